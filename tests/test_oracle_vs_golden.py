@@ -1,0 +1,138 @@
+"""The CPU oracle (oracle/vv_oracle.py) against fixtures captured from the reference's own modules
+(oracle/gen/make_golden.py).  CPU only.  Tolerances: fp32, different summation order only."""
+import numpy as np
+import torch
+
+from conftest import load_golden, rel_rms
+from oracle import vv_oracle as O
+
+TOL = 2e-5
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+def test_scheduler_tables_and_trajectory():
+    g = load_golden("scheduler")
+    ac = O.cosine_alphas_cumprod(1000)
+    np.testing.assert_allclose(ac.numpy(), g["alphas_cumprod"], rtol=0, atol=0)
+    for n in (10, 20, 50):
+        ts, sig = O.dpm_set_timesteps(ac, n)
+        assert ts.tolist() == g[f"timesteps_{n}"].tolist()
+        np.testing.assert_array_equal(sig.numpy(), g[f"sigmas_{n}"])
+    # known answers quoted in SURVEY.md §8a row 4
+    ts, sig = O.dpm_set_timesteps(ac, 20)
+    assert ts[:3].tolist() == [999, 949, 899] and ts[-1] == 50
+    assert abs(float(sig[1]) - 12.807271) < 1e-5 and float(sig[-1]) == 0.0
+    for n in (10, 20):
+        _, coefs = O.make_dpm_tables(dict(ddpm_steps=1000), n)
+        assert [c["order"] for c in coefs] == [1] + [2] * (n - 2) + [1]
+        x = t(g[f"traj_x0_{n}"])
+        m_prev = None
+        for i in range(n):
+            x, m_prev = O.dpm_step(coefs[i], x, 0.1 * x, m_prev)
+            assert rel_rms(x.numpy(), g[f"traj_{n}"][i]) < 1e-5, (n, i)
+
+
+def test_head_forward(tiny_cfg, tiny_weights):
+    g = load_golden("head_tiny")
+    cfg = tiny_cfg.as_dict()
+    for tt in (999, 500, 50):
+        out = O.head_forward(tiny_weights, cfg, t(g["x"]), torch.full((3,), float(tt)), t(g["cond"]))
+        assert rel_rms(out.numpy(), g[f"out_t{tt}"]) < TOL
+
+
+def test_sample_speech_tokens(tiny_cfg, tiny_weights):
+    g = load_golden("sample_tiny")
+    cfg = tiny_cfg.as_dict()
+    for n in (10, 20):
+        for cs in (1.0, 1.3, 2.0):
+            lat = O.sample_speech_tokens(tiny_weights, cfg, t(g["cond"]), t(g["ncond"]), t(g["noise"]), cs, n)
+            assert rel_rms(lat.numpy(), g[f"latent_n{n}_cfg{cs}"]) < 1e-4, (n, cs)
+
+
+def test_decoder_streaming_and_full(tiny_cfg, tiny_weights):
+    g = load_golden("decoder_tiny")
+    cfg = tiny_cfg.as_dict()
+    st = O.ConvState()
+    for f in range(g["latents"].shape[0]):
+        if f == int(g["reset_before"]):
+            st.zero()
+        wav = O.tokenizer_decoder(tiny_weights, cfg, t(g["latents"][f])[:, None], st)
+        assert wav.shape == (1, tiny_cfg.hop)
+        assert rel_rms(wav[0].numpy(), g["wav_stream"][f]) < TOL, f
+    full = O.tokenizer_decoder(tiny_weights, cfg, t(g["latents"][:5]).t(), None)
+    assert rel_rms(full[0].numpy(), g["wav_full5"]) < TOL
+    # the invariant the reference itself satisfies: streaming == non-streaming
+    assert rel_rms(g["wav_stream"][:5].reshape(-1), g["wav_full5"]) < 1e-5
+
+
+def test_semantic_streaming_full_and_ragged_acoustic(tiny_cfg, tiny_weights):
+    g = load_golden("semantic_tiny")
+    cfg = tiny_cfg.as_dict()
+    st = O.ConvState()
+    for f in range(g["wav"].shape[0]):
+        if f == int(g["reset_before"]):
+            st.zero()
+        feat = O.semantic_encode(tiny_weights, cfg, t(g["wav"][f])[None], st)
+        assert rel_rms(feat[0].numpy(), g["feat_stream"][f]) < TOL, f
+    full = O.semantic_encode(tiny_weights, cfg, t(g["wav"][:4].reshape(1, -1)), None)
+    assert rel_rms(full.numpy(), g["feat_full4"]) < TOL
+    ac = O.acoustic_encode(tiny_weights, cfg, t(g["ragged_wav"])[None])
+    assert ac.shape == g["ragged_acoustic_mean"].shape
+    assert rel_rms(ac.numpy(), g["ragged_acoustic_mean"]) < TOL
+
+
+def test_connectors(tiny_weights):
+    g = load_golden("connector_tiny")
+    assert rel_rms(O.connector(tiny_weights, "model.acoustic_connector.", t(g["a"])).numpy(), g["a_out"]) < TOL
+    assert rel_rms(O.connector(tiny_weights, "model.semantic_connector.", t(g["s"])).numpy(), g["s_out"]) < TOL
+
+
+def test_llm_prefill_and_decode(tiny_cfg, tiny_weights):
+    g = load_golden("llm_tiny")
+    cfg = tiny_cfg.as_dict()
+    emb = tiny_weights["model.language_model.embed_tokens.weight"]
+    kv = O.KVCache(tiny_cfg.layers)
+    h = O.llm_forward(tiny_weights, cfg, emb[t(g["ids"])], kv, 0)
+    assert rel_rms(h.numpy(), g["prefill_hidden"]) < TOL
+    logits = h[-1] @ O.lm_head_weight(tiny_weights, cfg).t()
+    assert rel_rms(logits.numpy(), g["prefill_logits"]) < TOL
+    for i in range(3):
+        h = O.llm_forward(tiny_weights, cfg, t(g["decode_embeds"][i])[None], kv, kv.length)
+        assert rel_rms(h[0].numpy(), g["decode_hidden"][i]) < TOL, i
+    assert rel_rms(kv.k[0].numpy(), g["k_cache_l0"]) < TOL
+    assert rel_rms(kv.v[1].numpy(), g["v_cache_l1"]) < TOL
+
+
+def test_process_speech_inputs(tiny_cfg, tiny_weights):
+    g = load_golden("speech_inputs_tiny")
+    feats, conn = O.process_speech_inputs(tiny_weights, tiny_cfg.as_dict(), t(g["wav"]), t(g["masks"]),
+                                          t(g["std_noise"]), t(g["eps_noise"]))
+    assert rel_rms(feats.numpy(), g["feats"]) < TOL
+    assert rel_rms(conn.numpy(), g["connected"]) < TOL
+
+
+def test_generate_loop_trace(tiny_cfg, tiny_weights):
+    """The loop restatement against the hand-driven reference trace, which performs the reference's own
+    negative-branch attention-mask / KV surgery: pins 'reset == truncate to empty context'."""
+    g = load_golden("loop_trace_tiny")
+    cfg = tiny_cfg.as_dict()
+    ST, E, D, EOS = [int(v) for v in g["special"]]
+    special = dict(speech_start=ST, speech_end=E, speech_diffusion=D, eos=EOS)
+    _, conn = O.process_speech_inputs(tiny_weights, cfg, t(g["voice"]), t(g["speech_masks"]), t(g["std_noise"]), t(g["eps_noise"]))
+    res = O.generate(tiny_weights, cfg, g["ids"].tolist(), t(g["speech_input_mask"]), conn, special, t(g["noise"]),
+                     cfg_scale=float(g["cfg_scale"]), n_steps=int(g["n_steps"]), forced_tokens=g["forced"].tolist(),
+                     keep_trace=True)
+    assert res.sequences[len(g["ids"]):] == g["tokens"].tolist()
+    frames = [r for r in res.trace if "latent" in r]
+    assert len(frames) == g["latent"].shape[0] == 5
+    for i, r in enumerate(frames):
+        assert rel_rms(r["cond"].numpy(), g["cond"][i]) < 1e-4, i
+        assert rel_rms(r["ncond"].numpy(), g["ncond"][i]) < 1e-4, i
+        assert rel_rms(r["latent"].numpy(), g["latent"][i]) < 2e-4, i
+        assert rel_rms(r["wav"].numpy(), g["wav"][i]) < 5e-4, i
+        assert rel_rms(r["sem"].numpy(), g["sem"][i]) < 5e-4, i
+    for i in range(g["next_embeds"].shape[0]):
+        assert rel_rms(res.trace[i]["next_embeds"].numpy(), g["next_embeds"][i]) < 5e-4, i
