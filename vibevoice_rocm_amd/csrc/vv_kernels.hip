@@ -1,0 +1,876 @@
+// vv_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the VibeVoice per-frame hot path and their launchers.
+//
+// Everything on this path at batch 1-2 is HBM-bandwidth bound (~2.5 flop/byte), so the kernels are
+// built around 64-wide wavefronts streaming each weight byte exactly once with 16-byte loads per lane, staging the
+// (tiny) activation vectors in LDS, reducing with wavefront shuffles, and fusing every elementwise neighbour
+// (RMSNorm / adaLN modulate / SiLU prologues; bias / GELU / SwiGLU / layer-scale / residual epilogues) into the
+// producing kernel.  MFMA is deliberately not used here: at M <= 8 rows the matrix cores cannot be fed.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "vv_hip.h"
+#include "vv_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int vv_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* vv_last_error(void) { return g_err; }
+extern "C" int vv_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(unsigned int u16) { return __uint_as_float(u16 << 16); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <typename WT> struct WL;
+template <> struct WL<float> {
+  static __device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+  static __device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+  }
+  static __device__ __forceinline__ float load1(const float* p) { return *p; }
+};
+template <> struct WL<bf16_t> {
+  static __device__ __forceinline__ void load8(const bf16_t* p, float (&o)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void load4(const bf16_t* p, float (&o)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ float load1(const bf16_t* p) { return bf2f(*p); }
+};
+
+__device__ __forceinline__ void lin_epilogue(const vv_lin_args& a, int m, int n, float v, float v2) {
+  if (a.bias) v += a.bias[n];
+  if (a.act == VV_ACT_GELU) v = gelu_f(v);
+  else if (a.act == VV_ACT_SWIGLU) v = silu_f(v) * v2;
+  if (a.gate) v *= a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n];
+  if (a.res) v += a.res[(int64_t)m * a.ldres + n];
+  a.out[(int64_t)m * a.ldo + n] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMV: M <= 8 rows of activations against a streamed weight matrix.
+//   block = 256 threads = 4 waves.  KSPLIT == 1: each wave owns RW whole weight rows (large N);
+//   KSPLIT == 4: the block owns RW rows and its 4 waves split K (small N, long K) and combine through LDS.
+//   x is staged (with its prologue applied) into LDS in chunks of KC elements so LDS use stays <= 32 KB.
+// ---------------------------------------------------------------------------------------------------------------
+#define GEMV_THREADS 256
+
+template <int M>
+__device__ __forceinline__ void row_stats(const vv_lin_args& a, float* red, float (&rstd)[M]) {
+  // rstd[m] = rsqrt(mean(x[m]^2) + eps), every thread gets all M values
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ss[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float* xr = a.x + (int64_t)m * a.ldx;
+    float s = 0.f;
+    for (int k = tid; k < a.k; k += GEMV_THREADS) { const float v = xr[k]; s += v * v; }
+    ss[m] = wave_sum(s);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) red[wave * M + m] = ss[m];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float t = red[m] + red[M + m] + red[2 * M + m] + red[3 * M + m];
+    rstd[m] = rsqrtf(t / (float)a.k + a.eps);
+  }
+  __syncthreads();
+}
+
+template <int M>
+__device__ __forceinline__ void stage_chunk(const vv_lin_args& a, float* xs, int kc0, int kc, int kcp, const float (&rstd)[M]) {
+  // xs[m][0..kcp) <- prologue(x[m][kc0 .. kc0+kc)), zero padded to kcp
+  for (int idx = threadIdx.x; idx < M * kcp; idx += GEMV_THREADS) {
+    const int m = idx / kcp, kk = idx - m * kcp;
+    float v = 0.f;
+    if (kk < kc) {
+      const int k = kc0 + kk;
+      v = a.x[(int64_t)m * a.ldx + k];
+      if (a.pro == VV_PRO_RMSNORM) {
+        v *= rstd[m];
+        if (a.norm_w) v *= a.norm_w[k];
+        if (a.mod_scale) v = v * (1.0f + a.mod_scale[(int64_t)m * a.ld_mod + k]) + a.mod_shift[(int64_t)m * a.ld_mod + k];
+      } else if (a.pro == VV_PRO_SILU) {
+        v = silu_f(v);
+      }
+    }
+    xs[idx] = v;
+  }
+}
+
+template <typename WT, int M, bool DUAL, int KSPLIT, int RW>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(const vv_lin_args a, const int KC) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* red = smem;                 // [4*M] stats scratch, then [4][RW][M][2] split-K scratch
+  float* xs = smem + 64 * 4;         // [M][KCP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.k, N = a.n;
+  const WT* __restrict__ W = reinterpret_cast<const WT*>(a.w);
+  const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.w2);
+
+  float rstd[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) rstd[m] = 1.f;
+  if (a.pro == VV_PRO_RMSNORM) row_stats<M>(a, red, rstd);
+
+  const int row0 = (KSPLIT == 1 ? (blockIdx.x * 4 + wave) : blockIdx.x) * RW;
+  float acc[RW][M], acc2[DUAL ? RW : 1][M];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int m = 0; m < M; ++m) { acc[r][m] = 0.f; if (DUAL) acc2[r][m] = 0.f; }
+
+  for (int kc0 = 0; kc0 < K; kc0 += KC) {
+    const int kc = min(KC, K - kc0);
+    const int kcp = (kc + 7) & ~7;
+    if (kc0 > 0) __syncthreads();
+    stage_chunk<M>(a, xs, kc0, kc, kcp, rstd);
+    __syncthreads();
+    const int kstart = (KSPLIT == 1 ? lane : (wave * 64 + lane)) * 8;
+    const int kstep = (KSPLIT == 1 ? 64 : 256) * 8;
+#pragma unroll 2
+    for (int k = kstart; k < kc; k += kstep) {
+      float w[RW][8], w2[DUAL ? RW : 1][8];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int n = min(row0 + r, N - 1);
+        WL<WT>::load8(W + (int64_t)n * K + kc0 + k, w[r]);
+        if (DUAL) WL<WT>::load8(W2 + (int64_t)n * K + kc0 + k, w2[r]);
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + m * kcp + k);
+        const float4 x1 = *reinterpret_cast<const float4*>(xs + m * kcp + k + 4);
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[r][m] = fmaf(w[r][j], xv[j], acc[r][m]);
+            if (DUAL) acc2[r][m] = fmaf(w2[r][j], xv[j], acc2[r][m]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int m = 0; m < M; ++m) { acc[r][m] = wave_sum(acc[r][m]); if (DUAL) acc2[r][m] = wave_sum(acc2[r][m]); }
+
+  if (KSPLIT == 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+        if (row0 + r < N) {
+#pragma unroll
+          for (int m = 0; m < M; ++m) lin_epilogue(a, m, row0 + r, acc[r][m], DUAL ? acc2[r][m] : 0.f);
+        }
+    }
+  } else {
+    __syncthreads();   // xs/red reuse
+    float* part = smem;  // [4][RW*M*2]
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          part[(wave * RW * M + r * M + m) * 2 + 0] = acc[r][m];
+          part[(wave * RW * M + r * M + m) * 2 + 1] = DUAL ? acc2[r][m] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid < RW * M) {
+      const int r = tid / M, m = tid - r * M;
+      if (row0 + r < N) {
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) { s += part[(w4 * RW * M + tid) * 2]; s2 += part[(w4 * RW * M + tid) * 2 + 1]; }
+        lin_epilogue(a, m, row0 + r, s, s2);
+      }
+    }
+  }
+}
+
+// generic (any K, any alignment) fallback: one wave per output row, scalar loads.  Only tiny shapes land here.
+template <typename WT>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_generic_kernel(const vv_lin_args a) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const WT* W = reinterpret_cast<const WT*>(a.w);
+  const WT* W2 = reinterpret_cast<const WT*>(a.w2);
+  for (int m = 0; m < a.m; ++m) {
+    const float* xr = a.x + (int64_t)m * a.ldx;
+    float rstd = 1.f;
+    if (a.pro == VV_PRO_RMSNORM) {
+      float s = 0.f;
+      for (int k = tid; k < a.k; k += GEMV_THREADS) s += xr[k] * xr[k];
+      s = wave_sum(s);
+      __syncthreads();
+      if (lane == 0) red[wave] = s;
+      __syncthreads();
+      rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)a.k + a.eps);
+    }
+    for (int n = blockIdx.x * 4 + wave; n < a.n; n += gridDim.x * 4) {
+      float s = 0.f, s2 = 0.f;
+      for (int k = lane; k < a.k; k += 64) {
+        float v = xr[k];
+        if (a.pro == VV_PRO_RMSNORM) {
+          v *= rstd;
+          if (a.norm_w) v *= a.norm_w[k];
+          if (a.mod_scale) v = v * (1.0f + a.mod_scale[(int64_t)m * a.ld_mod + k]) + a.mod_shift[(int64_t)m * a.ld_mod + k];
+        } else if (a.pro == VV_PRO_SILU) v = silu_f(v);
+        s = fmaf(WL<WT>::load1(W + (int64_t)n * a.k + k), v, s);
+        if (W2) s2 = fmaf(WL<WT>::load1(W2 + (int64_t)n * a.k + k), v, s2);
+      }
+      s = wave_sum(s); s2 = wave_sum(s2);
+      if (lane == 0) lin_epilogue(a, m, n, s, s2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM (M > 8): 64x64 output tile per 256-thread block, 4x4 micro-tile per thread, K stepped by 16 through LDS.
+// A rows may overlap (ldx < k): that is how dense Conv1d / ConvTranspose1d read their im2col view in place.
+// ---------------------------------------------------------------------------------------------------------------
+#define TM 64
+#define TN 64
+#define TK 16
+
+template <typename WT, bool DUAL, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const vv_lin_args a) {
+  __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];
+  __shared__ __attribute__((aligned(16))) float Ws[TK][TN + 4];
+  __shared__ __attribute__((aligned(16))) float Ws2[DUAL ? TK : 1][TN + 4];
+  __shared__ float rs[TM];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int M = a.m, N = a.n, K = a.k;
+  const WT* __restrict__ W = reinterpret_cast<const WT*>(a.w);
+  const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.w2);
+
+  if (a.pro == VV_PRO_RMSNORM) {
+    const int r = tid >> 2, q = tid & 3;
+    float s = 0.f;
+    if (m0 + r < M) {
+      const float* xr = a.x + (int64_t)(m0 + r) * a.ldx;
+      for (int k = q; k < K; k += 4) { const float v = xr[k]; s += v * v; }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (q == 0) rs[r] = rsqrtf(s / (float)K + a.eps);
+    __syncthreads();
+  }
+
+  float acc[4][4], acc2[DUAL ? 4 : 1][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[i][j] = 0.f; if (DUAL) acc2[i][j] = 0.f; }
+
+  const int lr = tid >> 2, lk = (tid & 3) * 4;   // this thread stages row lr, k offsets lk..lk+3 of both tiles
+  for (int k0 = 0; k0 < K; k0 += TK) {
+    float av[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f}, wv2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int kb = k0 + lk;
+    if (m0 + lr < M) {
+      const float* xr = a.x + (int64_t)(m0 + lr) * a.ldx + kb;
+      if (VEC && kb + 3 < K) {
+        const float4 v = *reinterpret_cast<const float4*>(xr);
+        av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (kb + i < K) av[i] = xr[i];
+      }
+      if (a.pro == VV_PRO_RMSNORM) {
+        const float r = rs[lr];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (kb + i < K) {
+          float v = av[i] * r;
+          if (a.norm_w) v *= a.norm_w[kb + i];
+          if (a.mod_scale) v = v * (1.0f + a.mod_scale[(int64_t)(m0 + lr) * a.ld_mod + kb + i]) + a.mod_shift[(int64_t)(m0 + lr) * a.ld_mod + kb + i];
+          av[i] = v;
+        }
+      } else if (a.pro == VV_PRO_SILU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = silu_f(av[i]);
+      }
+    }
+    if (n0 + lr < N) {
+      const WT* wr = W + (int64_t)(n0 + lr) * K + kb;
+      if (VEC && kb + 3 < K) {
+        WL<WT>::load4(wr, wv);
+        if (DUAL) WL<WT>::load4(W2 + (int64_t)(n0 + lr) * K + kb, wv2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (kb + i < K) {
+          wv[i] = WL<WT>::load1(wr + i);
+          if (DUAL) wv2[i] = WL<WT>::load1(W2 + (int64_t)(n0 + lr) * K + kb + i);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { As[lk + i][lr] = av[i]; Ws[lk + i][lr] = wv[i]; if (DUAL) Ws2[lk + i][lr] = wv2[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; ++kk) {
+      const float4 av4 = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+      const float4 bv4 = *reinterpret_cast<const float4*>(&Ws[kk][tx * 4]);
+      const float ar[4] = {av4.x, av4.y, av4.z, av4.w};
+      const float br[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+      float br2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (DUAL) { const float4 c = *reinterpret_cast<const float4*>(&Ws2[kk][tx * 4]); br2[0] = c.x; br2[1] = c.y; br2[2] = c.z; br2[3] = c.w; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[i][j] = fmaf(ar[i], br[j], acc[i][j]); if (DUAL) acc2[i][j] = fmaf(ar[i], br2[j], acc2[i][j]); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n < N) lin_epilogue(a, m, n, acc[i][j], DUAL ? acc2[i][j] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------------------------
+template <typename WT, int M, bool DUAL>
+static int launch_gemv(const vv_lin_args& a, hipStream_t s) {
+  const int K = a.k, N = a.n;
+  int KC = (8192 / M) & ~1023;                 // <= 32 KB of staged x
+  if (KC < 1024) KC = 1024;
+  if (KC > K) KC = (K + 7) & ~7;
+  const size_t lds = (size_t)(256 + M * KC) * sizeof(float);
+  const bool splitk = (N < 4096 && K >= 2048);
+  if (splitk) {
+    if (N >= 1024) { hipLaunchKernelGGL((gemv_kernel<WT, M, DUAL, 4, 2>), dim3((N + 1) / 2), dim3(GEMV_THREADS), lds, s, a, KC); }
+    else           { hipLaunchKernelGGL((gemv_kernel<WT, M, DUAL, 4, 1>), dim3(N), dim3(GEMV_THREADS), lds, s, a, KC); }
+  } else {
+    if ((int64_t)N >= 8192 && M <= 4 && !(DUAL && M > 2)) {
+      hipLaunchKernelGGL((gemv_kernel<WT, M, DUAL, 1, 2>), dim3((N + 7) / 8), dim3(GEMV_THREADS), lds, s, a, KC);
+    } else {
+      hipLaunchKernelGGL((gemv_kernel<WT, M, DUAL, 1, 1>), dim3((N + 3) / 4), dim3(GEMV_THREADS), lds, s, a, KC);
+    }
+  }
+  return 0;
+}
+
+template <typename WT, bool DUAL>
+static int launch_gemv_m(const vv_lin_args& a, hipStream_t s) {
+  switch (a.m) {
+    case 1: return launch_gemv<WT, 1, DUAL>(a, s);
+    case 2: return launch_gemv<WT, 2, DUAL>(a, s);
+    case 3: return launch_gemv<WT, 3, DUAL>(a, s);
+    case 4: return launch_gemv<WT, 4, DUAL>(a, s);
+    case 5: return launch_gemv<WT, 5, DUAL>(a, s);
+    case 6: return launch_gemv<WT, 6, DUAL>(a, s);
+    case 7: return launch_gemv<WT, 7, DUAL>(a, s);
+    default: return launch_gemv<WT, 8, DUAL>(a, s);
+  }
+}
+
+template <typename WT>
+static int launch_linear(const vv_lin_args& a, hipStream_t s) {
+  const bool dual = a.w2 != nullptr;
+  const size_t wsz = sizeof(WT);
+  const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
+  if (a.m <= 8) {
+    const bool fast = (a.k % 8 == 0) && w_al16 && ((a.k * wsz) % 16 == 0);
+    if (fast) return dual ? launch_gemv_m<WT, true>(a, s) : launch_gemv_m<WT, false>(a, s);
+    int blocks = (a.n + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((gemv_generic_kernel<WT>), dim3(blocks), dim3(GEMV_THREADS), 0, s, a);
+    return 0;
+  }
+  const bool vec = (a.k % 4 == 0) && (a.ldx % 4 == 0) && ((uintptr_t)a.x % 16 == 0) && w_al16;
+  dim3 grid((a.n + TN - 1) / TN, (a.m + TM - 1) / TM);
+  if (grid.y > 65535u) return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: m=%d rows exceed one launch (split the call)", a.m);
+  if (dual) {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<WT, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<WT, true, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((gemm_kernel<WT, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<WT, false, false>), grid, dim3(256), 0, s, a);
+  }
+  return 0;
+}
+
+extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
+  if (!a || !a->x || !a->w || !a->out) return vv_set_error(VV_E_ARG, "vv_linear: null pointer");
+  if (a->m <= 0 || a->n <= 0 || a->k <= 0) return vv_set_error(VV_E_ARG, "vv_linear: bad shape m=%d n=%d k=%d", a->m, a->n, a->k);
+  if (a->act == VV_ACT_SWIGLU && !a->w2) return vv_set_error(VV_E_ARG, "vv_linear: SWIGLU needs w2");
+  if (a->act != VV_ACT_SWIGLU && a->w2) return vv_set_error(VV_E_ARG, "vv_linear: w2 given without SWIGLU");
+  if (a->mod_scale && (!a->mod_shift || a->pro != VV_PRO_RMSNORM)) return vv_set_error(VV_E_ARG, "vv_linear: modulate needs RMSNORM prologue and shift");
+  if (a->m > 8 && a->ldx == 0) return vv_set_error(VV_E_ARG, "vv_linear: broadcast rows (ldx=0) only for m<=8");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (a->wdt == VV_F32) rc = launch_linear<float>(*a, s);
+  else if (a->wdt == VV_BF16) rc = launch_linear<bf16_t>(*a, s);
+  else return vv_set_error(VV_E_ARG, "vv_linear: bad wdt %d", a->wdt);
+  if (rc) return rc;
+  VV_CHECK_LAUNCH("vv_linear");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE + KV store, decode attention
+// ---------------------------------------------------------------------------------------------------------------
+template <typename KT> __device__ __forceinline__ void kv_store(KT* p, float v);
+template <> __device__ __forceinline__ void kv_store<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void kv_store<bf16_t>(bf16_t* p, float v) {
+  const __hip_bfloat16 b = __float2bfloat16(v);
+  *p = *reinterpret_cast<const bf16_t*>(&b);
+}
+
+template <typename KT>
+__global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
+                                                         const float* inv_freq, const int* lens, const int* cache_rows) {
+  const int r = blockIdx.x;
+  const int d = kv.head_dim, half = d >> 1;
+  const int pos = lens[r];
+  const int crow = cache_rows ? cache_rows[r] : r;
+  float* row = qkv + (int64_t)r * ld;
+  const int nq = heads * half, nk = kv.kv_heads * half;
+  KT* kc = reinterpret_cast<KT*>(kv.k);
+  KT* vc = reinterpret_cast<KT*>(kv.v);
+  const int64_t base = (((int64_t)layer * kv.rows + crow) * kv.kv_heads) * kv.s_max * d;
+  for (int idx = threadIdx.x; idx < nq + nk; idx += blockDim.x) {
+    const bool isq = idx < nq;
+    const int j = isq ? idx : idx - nq;
+    const int h = j / half, i = j - h * half;
+    float* p = row + (isq ? 0 : heads * d) + h * d;
+    const float ang = (float)pos * inv_freq[i];
+    const float c = cosf(ang), s = sinf(ang);
+    const float x1 = p[i], x2 = p[i + half];
+    const float y1 = x1 * c - x2 * s;         // q*cos + rotate_half(q)*sin, first half: -x2
+    const float y2 = x2 * c + x1 * s;         // second half: +x1
+    if (isq) { p[i] = y1; p[i + half] = y2; }
+    else {
+      KT* dst = kc + base + ((int64_t)h * kv.s_max + pos) * d;
+      kv_store<KT>(dst + i, y1);
+      kv_store<KT>(dst + i + half, y2);
+    }
+  }
+  const float* vrow = row + (heads + kv.kv_heads) * d;
+  for (int idx = threadIdx.x; idx < kv.kv_heads * d; idx += blockDim.x) {
+    const int h = idx / d, i = idx - h * d;
+    kv_store<KT>(vc + base + ((int64_t)h * kv.s_max + pos) * d + i, vrow[idx]);
+  }
+}
+
+extern "C" int vv_rope_store(float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+                             const int* lens, const int* cache_rows, vv_stream_t stream) {
+  if (!qkv || !kv || !inv_freq || !lens) return vv_set_error(VV_E_ARG, "vv_rope_store: null pointer");
+  if (layer < 0 || layer >= kv->layers || R <= 0) return vv_set_error(VV_E_ARG, "vv_rope_store: bad layer/R");
+  if (kv->head_dim % 2) return vv_set_error(VV_E_ARG, "vv_rope_store: odd head_dim");
+  hipStream_t s = (hipStream_t)stream;
+  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((rope_store_kernel<float>), dim3(R), dim3(256), 0, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, cache_rows);
+  else hipLaunchKernelGGL((rope_store_kernel<bf16_t>), dim3(R), dim3(256), 0, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, cache_rows);
+  VV_CHECK_LAUNCH("vv_rope_store");
+  return 0;
+}
+
+template <typename KT, int EPL>
+__device__ __forceinline__ void load_epl(const KT* p, float (&o)[EPL]) {
+  if constexpr (EPL == 8) WL<KT>::load8(p, o);
+  else WL<KT>::load4(p, o);
+}
+
+// One block per (query row, q head).  G lanes share one key (G * EPL == head_dim, EPL = 16 B of cache per lane),
+// so a wave covers 64/G keys per step with fully coalesced 16-byte loads; online softmax per lane group,
+// groups merged through LDS at the end.
+template <typename KT, int EPL>
+__global__ __launch_bounds__(256) void attn_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
+                                                   const int* lens, const int* cache_rows, float* out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int r = blockIdx.y, h = blockIdx.x;
+  const int d = kv.head_dim;
+  const int G = d / EPL;                       // lanes per key
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane % G, gi = lane / G;      // lane within group, group within wave
+  const int KPW = 64 / G;                      // keys per wave step
+  const int n_keys = lens[r] + 1;
+  const int crow = cache_rows ? cache_rows[r] : r;
+  const int kvh = h / (heads / kv.kv_heads);
+  const int64_t base = ((((int64_t)layer * kv.rows + crow) * kv.kv_heads + kvh) * kv.s_max) * d;
+  const KT* kc = reinterpret_cast<const KT*>(kv.k) + base;
+  const KT* vc = reinterpret_cast<const KT*>(kv.v) + base;
+  const float scale = rsqrtf((float)d);
+  float q[EPL];
+  const float* qp = qkv + (int64_t)r * ld + h * d + gl * EPL;
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) q[j] = qp[j] * scale;
+  float mmax = -INFINITY, lsum = 0.f, acc[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+  for (int s0 = wave * KPW; s0 < n_keys; s0 += 4 * KPW) {
+    const int s = s0 + gi;
+    const bool valid = s < n_keys;
+    float kx[EPL], vx[EPL];
+    const int sc = valid ? s : n_keys - 1;
+    load_epl<KT, EPL>(kc + (int64_t)sc * d + gl * EPL, kx);
+    load_epl<KT, EPL>(vc + (int64_t)sc * d + gl * EPL, vx);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) dot = fmaf(q[j], kx[j], dot);
+    for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (valid) {
+      const float mn = fmaxf(mmax, dot);
+      const float corr = expf(mmax - mn);      // exp(-inf) = 0 on the first key
+      const float p = expf(dot - mn);
+      lsum = lsum * corr + p;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vx[j], acc[j] * corr);
+      mmax = mn;
+    }
+  }
+  // merge the 4*KPW groups: sm = [ngroups][2 + d]
+  const int ng = 4 * KPW;
+  const int g = wave * KPW + gi;
+  float* rec = sm + (int64_t)g * (d + 2);
+  if (gl == 0) { rec[0] = mmax; rec[1] = lsum; }
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) rec[2 + gl * EPL + j] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < d; i += blockDim.x) {
+    float M = -INFINITY;
+    for (int gg = 0; gg < ng; ++gg) M = fmaxf(M, sm[(int64_t)gg * (d + 2)]);
+    float num = 0.f, den = 0.f;
+    for (int gg = 0; gg < ng; ++gg) {
+      const float* rr = sm + (int64_t)gg * (d + 2);
+      const float wgt = (rr[0] == -INFINITY) ? 0.f : expf(rr[0] - M);
+      den = fmaf(rr[1], wgt, den);
+      num = fmaf(rr[2 + i], wgt, num);
+    }
+    out[(int64_t)r * ldo + h * d + i] = num / den;
+  }
+}
+
+extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const int* lens,
+                       const int* cache_rows, float* out, int64_t ldo, vv_stream_t stream) {
+  if (!qkv || !kv || !lens || !out) return vv_set_error(VV_E_ARG, "vv_attn: null pointer");
+  if (layer < 0 || layer >= kv->layers || R <= 0 || heads % kv->kv_heads) return vv_set_error(VV_E_ARG, "vv_attn: bad layer/R/heads");
+  const int d = kv->head_dim;
+  const int epl = kv->kvdt == VV_F32 ? 4 : 8;
+  if (d % epl || 64 % (d / epl) || d / epl > 64) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn: head_dim %d unsupported for kv dtype %d", d, kv->kvdt);
+  const int G = d / epl, ng = 4 * (64 / G);
+  const size_t lds = (size_t)ng * (d + 2) * sizeof(float);
+  if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn: LDS %zu too large", lds);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(heads, R);
+  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_kernel<float, 4>), grid, dim3(256), lds, s, qkv, ld_qkv, heads, *kv, layer, lens, cache_rows, out, ldo);
+  else hipLaunchKernelGGL((attn_kernel<bf16_t, 8>), grid, dim3(256), lds, s, qkv, ld_qkv, heads, *kv, layer, lens, cache_rows, out, ldo);
+  VV_CHECK_LAUNCH("vv_attn");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Block1D mixer: out = x + gamma * (dwconv7(RMSNorm_c(x)) + b), channels-last, streaming history of normalised rows
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C,
+                                                          const float* norm_w, float eps, const float* dw_w, const float* dw_b,
+                                                          const float* gamma, float* hist, int TR) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [TR + 6][C] normalised rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = blockIdx.x * TR;
+  const int tr = min(TR, T - t0);
+  // rows t0-6 .. t0+tr-1 -> sm rows 0 .. tr+5
+  for (int rr = wave; rr < tr + 6; rr += 4) {
+    const int t = t0 - 6 + rr;
+    float* dst = sm + (int64_t)rr * C;
+    if (t < 0) {
+      for (int c = lane; c < C; c += 64) dst[c] = hist ? hist[(int64_t)(6 + t) * C + c] : 0.f;   // t in [-6,-1] -> hist row 6+t
+    } else {
+      const float* xr = x + (int64_t)t * C;
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
+      s = wave_sum(s);
+      const float rstd = rsqrtf(s / (float)C + eps);
+      for (int c = lane; c < C; c += 64) dst[c] = xr[c] * rstd * norm_w[c];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < tr * C; idx += blockDim.x) {
+    const int tt = idx / C, c = idx - tt * C;
+    float s = dw_b[c];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s = fmaf(dw_w[c * 7 + k], sm[(int64_t)(tt + k) * C + c], s);
+    const int64_t o = (int64_t)(t0 + tt) * C + c;
+    out[o] = x[o] + gamma[c] * s;
+  }
+  if (hist && blockIdx.x == 0) {
+    // new history = last 6 rows of [old history ; normalised x rows].  Block 0 is the only reader of hist (its halo,
+    // already copied into sm rows 0..5 before the barrier above), so it is also the only writer; rows outside its tile
+    // are re-normalised here.
+    for (int j = wave; j < 6; j += 4) {
+      const int src = T - 6 + j;             // row of x; negative -> old history row j+T
+      float* dst = hist + (int64_t)j * C;
+      if (src < 0) {
+        for (int c = lane; c < C; c += 64) dst[c] = sm[(int64_t)(j + T) * C + c];
+      } else if (src < tr) {
+        for (int c = lane; c < C; c += 64) dst[c] = sm[(int64_t)(src + 6) * C + c];
+      } else {
+        const float* xr = x + (int64_t)src * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
+        s = wave_sum(s);
+        const float rstd = rsqrtf(s / (float)C + eps);
+        for (int c = lane; c < C; c += 64) dst[c] = xr[c] * rstd * norm_w[c];
+      }
+    }
+  }
+}
+
+extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const float* norm_w, float eps, const float* dw_w,
+                              const float* dw_b, const float* gamma, float* hist, vv_stream_t stream) {
+  if (!x || !out || !norm_w || !dw_w || !dw_b || !gamma) return vv_set_error(VV_E_ARG, "vv_block_mixer: null pointer");
+  if (x == out) return vv_set_error(VV_E_ARG, "vv_block_mixer: in-place not allowed (halo rows)");
+  if (T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_block_mixer: bad shape");
+  int TR = 15360 / C - 6;                       // (TR + 6) * C * 4 <= 60 KB
+  if (TR > 64) TR = 64;
+  if (TR > T) TR = T;
+  if (TR < 1) TR = 1;
+  const size_t lds = (size_t)(TR + 6) * C * sizeof(float);
+  if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: C=%d too wide", C);
+  if (hist && TR < 6 && T > TR)   // blocks 1..5 would read hist while block 0 rewrites it
+    return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: streaming with C=%d needs T<=%d rows per call (got %d)", C, TR, T);
+  hipLaunchKernelGGL(block_mixer_kernel, dim3((T + TR - 1) / TR), dim3(256), lds, (hipStream_t)stream, x, out, T, C, norm_w, eps,
+                     dw_w, dw_b, gamma, hist, TR);
+  VV_CHECK_LAUNCH("vv_block_mixer");
+  return 0;
+}
+
+// pad[0:ctx] <- state; state <- last ctx rows of [state ; pad[ctx : ctx+T]]   (single block: ctx*C is tiny)
+__global__ __launch_bounds__(256) void conv_ctx_kernel(float* pad, float* state, int ctx, int T, int C) {
+  const int n = ctx * C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) pad[i] = state[i];
+  __syncthreads();
+  // virtual sequence V = pad[0 : ctx+T]; new state = V[T : T+ctx]
+  for (int i = threadIdx.x; i < n; i += blockDim.x) state[i] = pad[(int64_t)T * C + i];
+}
+
+extern "C" int vv_conv_ctx(float* pad, float* state, int ctx, int T, int C, vv_stream_t stream) {
+  if (!pad || !state || ctx <= 0 || T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_conv_ctx: bad args");
+  hipLaunchKernelGGL(conv_ctx_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pad, state, ctx, T, C);
+  VV_CHECK_LAUNCH("vv_conv_ctx");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small elementwise kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void affine_kernel(const float* x, float a, float b, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = fmaf(a, x[i], b);
+}
+extern "C" int vv_affine(const float* x, float a, float b, float* out, int64_t n, vv_stream_t stream) {
+  if (!x || !out || n <= 0) return vv_set_error(VV_E_ARG, "vv_affine: bad args");
+  int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(affine_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, a, b, out, n);
+  VV_CHECK_LAUNCH("vv_affine");
+  return 0;
+}
+
+// out[(i*rows_b + j), :] = a[j, :] + b[i, :]   for i < rows/rows_b, j < rows_b      (c = cond_proj(cond)[j] + t_emb[i])
+__global__ void add_rows_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n) {
+  const int r = blockIdx.x, i = r / rows_b, j = r - i * rows_b;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) out[(int64_t)r * n + c] = a[(int64_t)j * lda + c] + b[(int64_t)i * ldb + c];
+}
+extern "C" int vv_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream) {
+  if (!a || !b || !out || rows <= 0 || rows_b <= 0 || rows % rows_b || n <= 0) return vv_set_error(VV_E_ARG, "vv_add_rows: bad args");
+  hipLaunchKernelGGL(add_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, rows, rows_b, n);
+  VV_CHECK_LAUNCH("vv_add_rows");
+  return 0;
+}
+
+template <typename WT>
+__global__ void embed_row_kernel(const WT* table, int64_t hidden, const int* token, float* out) {
+  const int64_t t = *token;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < hidden; c += (int64_t)gridDim.x * blockDim.x)
+    out[c] = WL<WT>::load1(table + t * hidden + c);
+}
+extern "C" int vv_embed_row(const void* table, int wdt, int64_t hidden, const int* token, float* out, vv_stream_t stream) {
+  if (!table || !token || !out || hidden <= 0) return vv_set_error(VV_E_ARG, "vv_embed_row: bad args");
+  const int blocks = (int)((hidden + 255) / 256);
+  if (wdt == VV_F32) hipLaunchKernelGGL((embed_row_kernel<float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)table, hidden, token, out);
+  else hipLaunchKernelGGL((embed_row_kernel<bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table, hidden, token, out);
+  VV_CHECK_LAUNCH("vv_embed_row");
+  return 0;
+}
+
+extern "C" int vv_gather_rows(const void* table, int wdt, int64_t hidden, const int* ids_host, int n, void* out, vv_stream_t stream) {
+  if (!table || !ids_host || !out || n <= 0) return vv_set_error(VV_E_ARG, "vv_gather_rows: bad args");
+  const size_t esz = wdt == VV_F32 ? 4 : 2;
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipMemcpyAsync((char*)out + (size_t)i * hidden * esz, (const char*)table + (size_t)ids_host[i] * hidden * esz,
+                                  hidden * esz, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_gather_rows: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+// token = ids[argmax(logits)] with first-max-wins in ascending id order (torch.argmax over the masked full vocabulary,
+// modeling_vibevoice_inference.py:486-496); forced_token >= 0 overrides the choice (bench / fixture schedules).
+__global__ void argmax_ids_kernel(const float* logits, int n, const int* ids, int* token_out, const int* forced) {
+  if (threadIdx.x == 0) {
+    int best = 0;
+    for (int i = 1; i < n; ++i) {
+      if (logits[i] > logits[best] || (logits[i] == logits[best] && ids[i] < ids[best])) best = i;
+    }
+    const int f = forced ? *forced : -1;
+    *token_out = f >= 0 ? f : ids[best];
+  }
+}
+extern "C" int vv_argmax_ids(const float* logits, int n, const int* ids, int* token_out, const int* forced_token, vv_stream_t stream) {
+  if (!logits || !ids || !token_out || n <= 0) return vv_set_error(VV_E_ARG, "vv_argmax_ids: bad args");
+  hipLaunchKernelGGL(argmax_ids_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, logits, n, ids, token_out, forced_token);
+  VV_CHECK_LAUNCH("vv_argmax_ids");
+  return 0;
+}
+
+__global__ void dpm_step_kernel(const float* v, int64_t ldv, int ns, int latent, float cfg, float alpha_s, float sigma_s, float cx,
+                                float cd, float rinv, int order, float* x, float* m_prev) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns * latent) return;
+  const int smp = i / latent, c = i - smp * latent;
+  const float vc = v[(int64_t)smp * ldv + c], vu = v[(int64_t)(ns + smp) * ldv + c];
+  const float eps = vu + cfg * (vc - vu);
+  const float xx = x[i];
+  const float x0 = alpha_s * xx - sigma_s * eps;
+  float xn = cx * xx - cd * x0;
+  if (order == 2) xn -= 0.5f * cd * (rinv * (x0 - m_prev[i]));
+  x[i] = xn;
+  m_prev[i] = x0;
+}
+extern "C" int vv_dpm_step(const float* v, int64_t ldv, int n_samples, int latent, float cfg_scale, float alpha_s, float sigma_s,
+                           float cx, float cd, float rinv, int order, float* x, float* m_prev, vv_stream_t stream) {
+  if (!v || !x || !m_prev || n_samples <= 0 || latent <= 0) return vv_set_error(VV_E_ARG, "vv_dpm_step: bad args");
+  const int n = n_samples * latent;
+  hipLaunchKernelGGL(dpm_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, ldv, n_samples, latent, cfg_scale,
+                     alpha_s, sigma_s, cx, cd, rinv, order, x, m_prev);
+  VV_CHECK_LAUNCH("vv_dpm_step");
+  return 0;
+}
+
+// device-side bookkeeping so a whole frame can be replayed as one graph:
+// lens[0] (positive position) += 1; token == tok_start -> lens[1] = 0; token == tok_diffusion -> lens[1] += 1, frame += 1
+__global__ void advance_lens_kernel(int* lens, const int* token, int tok_start, int tok_diff, int* frame) {
+  if (threadIdx.x == 0) {
+    const int t = *token;
+    lens[0] += 1;
+    if (t == tok_start) lens[1] = 0;
+    else if (t == tok_diff) { lens[1] += 1; if (frame) *frame += 1; }
+  }
+}
+extern "C" int vv_advance_lens(int* lens, const int* token, int tok_start, int tok_diffusion, int* frame_counter, vv_stream_t stream) {
+  if (!lens || !token) return vv_set_error(VV_E_ARG, "vv_advance_lens: bad args");
+  hipLaunchKernelGGL(advance_lens_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lens, token, tok_start, tok_diffusion, frame_counter);
+  VV_CHECK_LAUNCH("vv_advance_lens");
+  return 0;
+}
+
+__global__ void copy_rows_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int n) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) out[(int64_t)r * ldo + c] = x[(int64_t)r * ldx + c];
+}
+extern "C" int vv_copy_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int n, vv_stream_t stream) {
+  if (!x || !out || rows <= 0 || n <= 0) return vv_set_error(VV_E_ARG, "vv_copy_rows: bad args");
+  int bx = (n + 255) / 256; if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(bx, rows), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, n);
+  VV_CHECK_LAUNCH("vv_copy_rows");
+  return 0;
+}
+
+// rows of RMSNorm (final LLM norm): out = x * rsqrt(mean x^2 + eps) * w
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* x, int64_t ldx, const float* w, float eps, int n, float* out, int64_t ldo) {
+  __shared__ float red[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (int64_t)r * ldx;
+  float s = 0.f;
+  for (int c = tid; c < n; c += blockDim.x) s += xr[c] * xr[c];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+  for (int c = tid; c < n; c += blockDim.x) out[(int64_t)r * ldo + c] = xr[c] * rstd * (w ? w[c] : 1.f);
+}
+int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s) {
+  hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, eps, n, out, ldo);
+  VV_CHECK_LAUNCH("vv_rmsnorm_rows");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hipGraph capture
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int vv_graph_begin(vv_stream_t stream) {
+  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  return 0;
+}
+extern "C" int vv_graph_end(vv_stream_t stream, void** graph_exec_out) {
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t ge = nullptr;
+  e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  *graph_exec_out = (void*)ge;
+  return 0;
+}
+extern "C" int vv_graph_launch(void* graph_exec, vv_stream_t stream) {
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+  return 0;
+}
+extern "C" int vv_graph_destroy(void* graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return 0;
+}

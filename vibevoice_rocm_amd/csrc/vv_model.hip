@@ -1,0 +1,406 @@
+// vv_model.hip — composite operators: each call enqueues the full launch sequence of one component of the
+// per-frame loop (LLM step, diffusion-head sampling, acoustic decoder, semantic/acoustic encoder, connectors)
+// on the caller's stream.  No host synchronisation, no allocation: capturable into one hipGraph per frame.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "vv_hip.h"
+#include "vv_common.h"
+
+namespace {
+
+struct Carver {   // carve 256-byte aligned float buffers out of a caller-provided workspace
+  char* p;
+  explicit Carver(void* base) : p(reinterpret_cast<char*>(base)) {}
+  float* take(size_t n_floats) {
+    float* r = reinterpret_cast<float*>(p);
+    p += (n_floats * sizeof(float) + 255) & ~(size_t)255;
+    return r;
+  }
+};
+inline size_t al(size_t n_floats) { return (n_floats * sizeof(float) + 255) & ~(size_t)255; }
+
+inline vv_lin_args lin_base(const float* x, int64_t ldx, int m, const void* w, int n, int k, int wdt, float* out, int64_t ldo) {
+  vv_lin_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = ldx; a.m = m; a.w = w; a.n = n; a.k = k; a.wdt = wdt; a.out = out; a.ldo = ldo;
+  return a;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Qwen2 decoder stack
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
+  if (!m || R <= 0) return 0;
+  const size_t qkv = (size_t)(m->heads + 2 * m->kv_heads) * m->head_dim;
+  return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter);
+}
+
+extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
+                              const int* cache_rows, float* out, int64_t ldo, void* ws, vv_stream_t stream) {
+  if (!m || !kv || !x || !lens || !out || !ws || !m->layer) return vv_set_error(VV_E_ARG, "vv_llm_forward: null pointer");
+  if (R <= 0) return vv_set_error(VV_E_ARG, "vv_llm_forward: R=%d", R);
+  if (kv->layers != m->layers || kv->kv_heads != m->kv_heads || kv->head_dim != m->head_dim)
+    return vv_set_error(VV_E_ARG, "vv_llm_forward: kv cache shape does not match the model");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = m->hidden, d = m->head_dim, qd = m->heads * d, qkvd = (m->heads + 2 * m->kv_heads) * d;
+  Carver c(ws);
+  float* h = c.take((size_t)R * H);
+  float* qkv = c.take((size_t)R * qkvd);
+  float* att = c.take((size_t)R * qd);
+  float* act = c.take((size_t)R * m->inter);
+  VV_TRY(vv_copy_rows(x, ldx, h, H, R, H, stream));
+  for (int l = 0; l < m->layers; ++l) {
+    const vv_llm_layer& L = m->layer[l];
+    vv_lin_args a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
+    a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
+    VV_TRY(vv_linear(&a, stream));
+    VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, m->inv_freq, lens, cache_rows, stream));
+    VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
+    a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
+    a.res = h; a.ldres = H;
+    VV_TRY(vv_linear(&a, stream));
+    a = lin_base(h, H, R, L.wgate, m->inter, H, m->wdt, act, m->inter);
+    a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln2; a.eps = m->rms_eps; a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
+    VV_TRY(vv_linear(&a, stream));
+    a = lin_base(act, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
+    a.res = h; a.ldres = H;
+    VV_TRY(vv_linear(&a, stream));
+  }
+  return vv_rmsnorm_rows(h, H, m->final_norm, m->rms_eps, R, H, out, ldo, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// diffusion head + DPM-Solver++ sampling
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t vv_head_ws_bytes(const vv_head* h, int n_steps) {
+  if (!h || n_steps <= 0) return 0;
+  const size_t R = 2 * (size_t)n_steps > 8 ? 2 * (size_t)n_steps : 8;
+  const size_t D = h->D;
+  return al(8 * D) /*c0*/ + al(R * D) /*c*/ + (size_t)h->layers * al(R * 3 * D) + al(R * 2 * D) + al(8 * D) /*hcur*/ +
+         al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + al(h->latent) /*x*/ + al(h->latent) /*m_prev*/;
+}
+
+// shared body: rows R (<= 8), modulation tables mod[l] [*, 3D] / modf [*, 2D] with row offset `mrow`
+static int head_body(const vv_head* h, const float* x, int64_t ldx, int R, float* const* mod, const float* modf, int64_t mrow,
+                     float* hcur, float* act, float* v, vv_stream_t stream) {
+  const int D = h->D;
+  vv_lin_args a = lin_base(x, ldx, R, h->noisy_proj, D, h->latent, h->wdt, hcur, D);
+  VV_TRY(vv_linear(&a, stream));
+  for (int l = 0; l < h->layers; ++l) {
+    const vv_head_layer& L = h->layer[l];
+    const float* ml = mod[l] + mrow * 3 * D;
+    a = lin_base(hcur, D, R, L.wgate, h->ffn, D, h->wdt, act, h->ffn);
+    a.pro = VV_PRO_RMSNORM; a.norm_w = L.norm_w; a.eps = h->eps;
+    a.mod_shift = ml; a.mod_scale = ml + D; a.ld_mod = 3 * D;
+    a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
+    VV_TRY(vv_linear(&a, stream));
+    a = lin_base(act, h->ffn, R, L.wdown, D, h->ffn, h->wdt, hcur, D);
+    a.gate = ml + 2 * D; a.gate_ld = 3 * D; a.res = hcur; a.ldres = D;
+    VV_TRY(vv_linear(&a, stream));
+  }
+  const float* mf = modf + mrow * 2 * D;
+  a = lin_base(hcur, D, R, h->final_linear, h->latent, D, h->wdt, v, h->latent);
+  a.pro = VV_PRO_RMSNORM; a.norm_w = nullptr; a.eps = h->eps;
+  a.mod_shift = mf; a.mod_scale = mf + D; a.ld_mod = 2 * D;
+  return vv_linear(&a, stream);
+}
+
+static int head_modulations(const vv_head* h, const float* c, int rows, float* const* mod, float* modf, vv_stream_t stream) {
+  const int D = h->D;
+  for (int l = 0; l < h->layers; ++l) {
+    vv_lin_args a = lin_base(c, D, rows, h->layer[l].adaln, 3 * D, D, h->wdt, mod[l], 3 * D);
+    a.pro = VV_PRO_SILU;
+    VV_TRY(vv_linear(&a, stream));
+  }
+  vv_lin_args a = lin_base(c, D, rows, h->final_adaln, 2 * D, D, h->wdt, modf, 2 * D);
+  a.pro = VV_PRO_SILU;
+  return vv_linear(&a, stream);
+}
+
+extern "C" int vv_head_forward(const vv_head* h, const float* x, const float* temb_rows, const float* cond, int R, float* v,
+                               void* ws, vv_stream_t stream) {
+  if (!h || !x || !temb_rows || !cond || !v || !ws) return vv_set_error(VV_E_ARG, "vv_head_forward: null pointer");
+  if (R <= 0 || R > 8 || h->layers > 16) return vv_set_error(VV_E_ARG, "vv_head_forward: R=%d (1..8)", R);
+  const int D = h->D;
+  Carver cv(ws);
+  float* c0 = cv.take(8 * (size_t)D);
+  float* c = cv.take(8 * (size_t)D);
+  float* mod[16];
+  for (int l = 0; l < h->layers; ++l) mod[l] = cv.take(8 * 3 * (size_t)D);
+  float* modf = cv.take(8 * 2 * (size_t)D);
+  float* hcur = cv.take(8 * (size_t)D);
+  float* act = cv.take(8 * (size_t)h->ffn);
+  vv_lin_args a = lin_base(cond, h->cond_dim, R, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
+  VV_TRY(vv_linear(&a, stream));
+  // c[r] = c0[r] + temb_rows[r]: rows_b = R with a single "step" whose b-row is row r -> use add_rows twice-free form
+  for (int r = 0; r < R; ++r) VV_TRY(vv_add_rows(c0 + (size_t)r * D, D, temb_rows + (size_t)r * D, D, c + (size_t)r * D, 1, 1, D, stream));
+  VV_TRY(head_modulations(h, c, R, mod, modf, stream));
+  return head_body(h, x, h->latent, R, mod, modf, 0, hcur, act, v, stream);
+}
+
+extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_cond, const float* noise, const float* temb,
+                              const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, void* ws, vv_stream_t stream) {
+  if (!h || !cond2 || !noise || !temb || !coef || !latent_out || !ws) return vv_set_error(VV_E_ARG, "vv_head_sample: null pointer");
+  if (n_steps <= 0 || h->layers > 16) return vv_set_error(VV_E_ARG, "vv_head_sample: bad n_steps/layers");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = h->D;
+  const size_t R = 2 * (size_t)n_steps > 8 ? 2 * (size_t)n_steps : 8;
+  Carver cv(ws);
+  float* c0 = cv.take(8 * (size_t)D);
+  float* c = cv.take(R * D);
+  float* mod[16];
+  for (int l = 0; l < h->layers; ++l) mod[l] = cv.take(R * 3 * D);
+  float* modf = cv.take(R * 2 * D);
+  float* hcur = cv.take(8 * (size_t)D);
+  float* act = cv.take(8 * (size_t)h->ffn);
+  float* v = cv.take(8 * (size_t)h->latent);
+  float* x = cv.take(h->latent);
+  float* mprev = cv.take(h->latent);
+  // step-invariant work hoisted out of the loop: cond_proj, c = cond_proj(cond) + t_emb(t_i), all adaLN modulations
+  vv_lin_args a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
+  VV_TRY(vv_linear(&a, stream));
+  VV_TRY(vv_add_rows(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+  VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, stream));
+  hipError_t e = hipMemcpyAsync(x, noise, (size_t)h->latent * 4, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_sample: %s", hipGetErrorString(e));
+  for (int i = 0; i < n_steps; ++i) {
+    // both rows (cond, uncond) read the same x: ldx = 0
+    VV_TRY(head_body(h, x, 0, 2, mod, modf, 2 * (int64_t)i, hcur, act, v, stream));
+    const vv_dpm_coef& k = coef[i];
+    VV_TRY(vv_dpm_step(v, h->latent, 1, h->latent, cfg_scale, k.alpha_s, k.sigma_s, k.cx, k.cd, k.rinv, k.order, x, mprev, stream));
+  }
+  e = hipMemcpyAsync(latent_out, x, (size_t)h->latent * 4, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_sample: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// causal conv tokenizer (decoder / encoder)
+// ---------------------------------------------------------------------------------------------------------------
+static inline int conv_ctx_of(const vv_conv& c) { return c.transposed ? 1 : c.kk - c.stride; }
+
+// max floats any [rows, C] activation (incl. left context and right padding) can take for an input of t_in steps
+static void convnet_sizes(const vv_convnet* net, int64_t t_in, int decoder, size_t* act_elems, size_t* hid_elems) {
+  size_t amax = 0, hmax = 0;
+  int64_t T = t_in;
+  for (int i = 0; i < net->n_stages; ++i) {
+    const vv_conv& cv = net->sample[i];
+    const int ctx = conv_ctx_of(cv);
+    size_t in_el = (size_t)(T + ctx + cv.kk + cv.stride) * cv.cin;   // generous right padding for ragged tails
+    if (in_el > amax) amax = in_el;
+    if (cv.transposed) T = T * cv.stride; else T = (T + cv.stride - 1) / cv.stride;
+    const size_t C = cv.cout;
+    size_t el = (size_t)(T + 8) * C;
+    if (el > amax) amax = el;
+    if (net->n_blocks[i] > 0 && (size_t)T * 4 * C > hmax) hmax = (size_t)T * 4 * C;
+  }
+  size_t in_el = (size_t)(T + 8 + net->head.kk) * net->head.cin;
+  if (in_el > amax) amax = in_el;
+  (void)decoder;
+  *act_elems = amax + 64;
+  *hid_elems = hmax + 64;
+}
+
+extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int decoder) {
+  if (!net || t_in <= 0) return 0;
+  size_t a, h;
+  convnet_sizes(net, t_in, decoder, &a, &h);
+  return 2 * al(a) + al(h);
+}
+
+static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*& cur, float*& other, float* hid,
+                      float* final_dst /* or null: leave in a ping-pong buffer */, vv_stream_t stream) {
+  const int nb = net->n_blocks[stage];
+  for (int j = 0; j < nb; ++j) {
+    const vv_block& B = net->blocks[stage][j];
+    VV_TRY(vv_block_mixer(cur, other, (int)T, C, B.norm_w, net->eps, B.dw_w, B.dw_b, B.gamma, B.hist, stream));
+    vv_lin_args a = lin_base(other, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
+    a.pro = VV_PRO_RMSNORM; a.norm_w = B.ffn_norm_w; a.eps = net->eps; a.bias = B.b1; a.act = VV_ACT_GELU;
+    VV_TRY(vv_linear(&a, stream));
+    float* dst = (j == nb - 1 && final_dst) ? final_dst : other;
+    a = lin_base(hid, 4 * C, (int)T, B.w2, C, 4 * C, net->wdt, dst, C);
+    a.bias = B.b2; a.gate = B.ffn_gamma; a.gate_ld = 0; a.res = other; a.ldres = C;
+    VV_TRY(vv_linear(&a, stream));
+    if (dst == other) { float* t = cur; cur = other; other = t; }   // result now in `cur`
+    else { cur = nullptr; }                                           // result went to final_dst
+  }
+  return 0;
+}
+
+// prepare the left context of a conv's padded input buffer `pad` (= [ctx rows | T rows already written by the producer])
+static int conv_left_ctx(const vv_conv& cv, float* pad, int64_t T, vv_stream_t stream) {
+  const int ctx = conv_ctx_of(cv);
+  if (ctx <= 0) return 0;
+  if (cv.state) return vv_conv_ctx(pad, cv.state, ctx, (int)T, cv.cin, stream);
+  hipError_t e = hipMemsetAsync(pad, 0, (size_t)ctx * cv.cin * 4, (hipStream_t)stream);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "conv_left_ctx: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, int T0, float pre_scale, float pre_bias, float* wav,
+                                  void* ws, vv_stream_t stream) {
+  if (!net || !latent || !wav || !ws) return vv_set_error(VV_E_ARG, "vv_decoder_forward: null pointer");
+  if (T0 <= 0 || net->n_stages < 1 || net->n_stages > VV_MAX_STAGES) return vv_set_error(VV_E_ARG, "vv_decoder_forward: bad T/stages");
+  size_t ael, hel;
+  convnet_sizes(net, T0, 1, &ael, &hel);
+  Carver cvr(ws);
+  float* A = cvr.take(ael);
+  float* Bf = cvr.take(ael);
+  float* hid = cvr.take(hel);
+  int64_t T = T0;
+  // stem input: padded [6 + T, vae] in A
+  const vv_conv& stem = net->sample[0];
+  if (stem.transposed || stem.stride != 1) return vv_set_error(VV_E_ARG, "vv_decoder_forward: stem must be a stride-1 conv");
+  float* pad = A;
+  VV_TRY(vv_affine(latent, pre_scale, pre_bias, pad + (size_t)conv_ctx_of(stem) * stem.cin, (int64_t)T * stem.cin, stream));
+  float* cur = nullptr;     // current activation buffer, `pad` holds the next conv's input
+  float* other = nullptr;
+  for (int i = 0; i < net->n_stages; ++i) {
+    const vv_conv& cv = net->sample[i];
+    VV_TRY(conv_left_ctx(cv, pad, T, stream));
+    float* outb = (pad == A) ? Bf : A;
+    vv_lin_args a;
+    if (cv.transposed) {
+      a = lin_base(pad, cv.cin, (int)T, cv.w, cv.stride * cv.cout, 2 * cv.cin, net->wdt, outb, (int64_t)cv.stride * cv.cout);
+      a.bias = cv.b;
+      VV_TRY(vv_linear(&a, stream));
+      T *= cv.stride;
+    } else {
+      a = lin_base(pad, (int64_t)cv.stride * cv.cin, (int)T, cv.w, cv.cout, cv.kk * cv.cin, net->wdt, outb, cv.cout);
+      a.bias = cv.b;
+      VV_TRY(vv_linear(&a, stream));
+    }
+    cur = outb;
+    other = (cur == A) ? Bf : A;
+    const int C = cv.cout;
+    const vv_conv& nxt = (i + 1 < net->n_stages) ? net->sample[i + 1] : net->head;
+    const int nctx = conv_ctx_of(nxt);
+    if (net->n_blocks[i] > 0) {
+      // the last block writes straight into the next conv's padded input; which buffer that is depends on block parity:
+      // block j reads cur -> writes other, then they swap.  The last block's mixer output sits in `other_last`, its
+      // result may go anywhere except that buffer and hid: use the buffer holding the (dead) input of that block.
+      const int nb = net->n_blocks[i];
+      float* last_in = (nb % 2 == 1) ? cur : other;       // input buffer of the last block
+      float* dst = last_in + (size_t)nctx * C;
+      // dst overlaps last_in shifted by nctx rows; the last block's lin2 reads only hid and the mixer output, so the
+      // dead input buffer can be overwritten.
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, dst, stream));
+      pad = last_in;
+    } else {
+      hipError_t e = hipMemcpyAsync(other + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+      if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_decoder_forward: %s", hipGetErrorString(e));
+      pad = other;
+    }
+  }
+  const vv_conv& hd = net->head;
+  VV_TRY(conv_left_ctx(hd, pad, T, stream));
+  vv_lin_args a = lin_base(pad, (int64_t)hd.stride * hd.cin, (int)T, hd.w, hd.cout, hd.kk * hd.cin, net->wdt, wav, hd.cout);
+  a.bias = hd.b;
+  return vv_linear(&a, stream);
+}
+
+extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64_t T0, float* feat, void* ws, vv_stream_t stream) {
+  if (!net || !wav || !feat || !ws) return vv_set_error(VV_E_ARG, "vv_encoder_forward: null pointer");
+  if (T0 <= 0 || net->n_stages < 1 || net->n_stages > VV_MAX_STAGES) return vv_set_error(VV_E_ARG, "vv_encoder_forward: bad T/stages");
+  hipStream_t s = (hipStream_t)stream;
+  size_t ael, hel;
+  convnet_sizes(net, T0, 0, &ael, &hel);
+  Carver cvr(ws);
+  float* A = cvr.take(ael);
+  float* Bf = cvr.take(ael);
+  float* hid = cvr.take(hel);
+  int64_t T = T0;
+  const vv_conv& stem = net->sample[0];
+  float* pad = A;
+  hipError_t e = hipMemcpyAsync(pad + (size_t)conv_ctx_of(stem) * stem.cin, wav, (size_t)T * stem.cin * 4, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
+  float* cur = nullptr;
+  float* other = nullptr;
+  for (int i = 0; i <= net->n_stages; ++i) {
+    const bool is_head = (i == net->n_stages);
+    const vv_conv& cv = is_head ? net->head : net->sample[i];
+    if (cv.transposed) return vv_set_error(VV_E_ARG, "vv_encoder_forward: transposed conv in an encoder");
+    const int ctx = conv_ctx_of(cv);
+    VV_TRY(conv_left_ctx(cv, pad, T, stream));
+    // output length as the reference's non-streaming padding rule gives it (modular_vibevoice_tokenizer.py:127-133);
+    // for streaming frames T is a multiple of the stride and there is no tail.
+    const int64_t Tout = (T + cv.stride - 1) / cv.stride;
+    const int64_t need = (Tout - 1) * cv.stride + cv.kk;        // rows of the padded buffer the conv reads
+    const int64_t have = ctx + T;
+    if (need > have) {
+      e = hipMemsetAsync(pad + (size_t)have * cv.cin, 0, (size_t)(need - have) * cv.cin * 4, s);
+      if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
+    }
+    float* outb = is_head ? feat : ((pad == A) ? Bf : A);
+    vv_lin_args a = lin_base(pad, (int64_t)cv.stride * cv.cin, (int)Tout, cv.w, cv.cout, cv.kk * cv.cin, net->wdt, outb, cv.cout);
+    a.bias = cv.b;
+    VV_TRY(vv_linear(&a, stream));
+    if (is_head) break;
+    T = Tout;
+    cur = outb;
+    other = (cur == A) ? Bf : A;
+    const int C = cv.cout;
+    const vv_conv& nxt = (i + 1 < net->n_stages) ? net->sample[i + 1] : net->head;
+    const int nctx = conv_ctx_of(nxt);
+    if (net->n_blocks[i] > 0) {
+      const int nb = net->n_blocks[i];
+      float* last_in = (nb % 2 == 1) ? cur : other;
+      float* dst = last_in + (size_t)nctx * C;
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, dst, stream));
+      pad = last_in;
+    } else {
+      e = hipMemcpyAsync(other + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
+      pad = other;
+    }
+  }
+  return 0;
+}
+
+extern "C" int vv_convnet_reset(const vv_convnet* net, vv_stream_t stream) {
+  if (!net) return vv_set_error(VV_E_ARG, "vv_convnet_reset: null");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i <= net->n_stages; ++i) {
+    const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
+    if (cv.state) {
+      hipError_t e = hipMemsetAsync(cv.state, 0, (size_t)conv_ctx_of(cv) * cv.cin * 4, s);
+      if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_convnet_reset: %s", hipGetErrorString(e));
+    }
+    if (i < net->n_stages) {
+      for (int j = 0; j < net->n_blocks[i]; ++j) {
+        const vv_block& B = net->blocks[i][j];
+        if (B.hist) {
+          hipError_t e = hipMemsetAsync(B.hist, 0, (size_t)6 * net->sample[i].cout * 4, s);
+          if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_convnet_reset: %s", hipGetErrorString(e));
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SpeechConnector
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int vv_connector_forward(const vv_connector* c, const float* x, int R, float* out, int accumulate, float* ws, vv_stream_t stream) {
+  if (!c || !x || !out || !ws || R <= 0) return vv_set_error(VV_E_ARG, "vv_connector_forward: bad args");
+  vv_lin_args a = lin_base(x, c->din, R, c->fc1, c->hidden, c->din, c->wdt, ws, c->hidden);
+  a.bias = c->b1;
+  VV_TRY(vv_linear(&a, stream));
+  a = lin_base(ws, c->hidden, R, c->fc2, c->hidden, c->hidden, c->wdt, out, c->hidden);
+  a.pro = VV_PRO_RMSNORM; a.norm_w = c->norm_w; a.eps = 1e-6f; a.bias = c->b2;
+  if (accumulate) { a.res = out; a.ldres = c->hidden; }
+  return vv_linear(&a, stream);
+}
+
+extern "C" size_t vv_sizeof(const char* name) {
+  if (!name) return 0;
+#define S(t) if (!strcmp(name, #t)) return sizeof(t);
+  S(vv_lin_args) S(vv_kv) S(vv_llm_layer) S(vv_llm) S(vv_head_layer) S(vv_head) S(vv_dpm_coef) S(vv_block) S(vv_conv) S(vv_convnet) S(vv_connector)
+#undef S
+  return 0;
+}

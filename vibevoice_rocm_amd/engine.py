@@ -1,0 +1,327 @@
+"""Per-GPU VibeVoice engine: device state + the launch sequences of the per-frame loop on the HIP C ABI.
+
+One Engine = one utterance stream on one MI355X (dialogues shard across GPUs, batch 1 per GPU).
+Everything numerical goes through libvv_hip.so; torch only owns device memory, the stream and pinned staging.
+
+Per generated token (reference loop: modeling_vibevoice_inference.py:430-673):
+  graph A  positive AND negative Qwen2 decode as ONE batch-2 weight pass (the negative row is speculative: it is
+           committed only if the chosen token is speech_diffusion, exactly when the reference runs it, :575-587)
+           -> 4/5 constrained logits -> argmax -> device-side position bookkeeping
+  host     reads the 4-byte token (the only sync of the frame) and runs the reference's token state machine
+  graph B  (speech_diffusion) CFG diffusion sampling -> acoustic decode -> semantic encode -> connectors -> next embedding
+  graph C  (otherwise) next embedding = embed_tokens[token]
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .config import VVConfig
+from .schedule import DPMSolverMultistepScheduler, timestep_sinusoid
+from .weights import DeviceWeights
+
+
+class Engine:
+    def __init__(self, cfg: VVConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", dtype=torch.bfloat16,
+                 kv_dtype: Optional[torch.dtype] = None, use_graphs: bool = True, bf16_timestep_quirk: Optional[bool] = None):
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.VVError("the VibeVoice MI355X engine needs a GPU device (there is no CPU path)")
+        self.dtype = dtype
+        self.kv_dtype = kv_dtype or dtype
+        self.use_graphs = use_graphs
+        self.bf16_t_quirk = (dtype == torch.bfloat16) if bf16_timestep_quirk is None else bf16_timestep_quirk
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.sync_in()
+        with torch.cuda.stream(self.stream):
+            self.w = DeviceWeights(cfg, state_dict, self.device, dtype)
+            H = cfg.hidden
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self.x2 = torch.zeros(2, H, **f32)            # input embedding of the step, rows {positive, negative}
+            self.hidden2 = torch.zeros(2, H, **f32)       # final-normed hidden states = {condition, negative condition}
+            self.lens = torch.zeros(2, dtype=torch.int32, device=self.device)     # positions {positive, negative}
+            self.frame_ctr = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.token_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.forced_dev = torch.full((1,), -1, dtype=torch.int32, device=self.device)
+            self.noise_dev = torch.zeros(cfg.latent, **f32)
+            self.latent = torch.zeros(cfg.latent, **f32)
+            self.wav = torch.zeros(cfg.hop, **f32)
+            self.sem = torch.zeros(cfg.sem_dim, **f32)
+            self.conn_ws = torch.zeros(8 * H, **f32)
+            self.logits = torch.zeros(8, **f32)
+        self.token_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.forced_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        self.noise_host = torch.zeros(cfg.latent, dtype=torch.float32).pin_memory()
+        self.scheduler = DPMSolverMultistepScheduler(num_train_timesteps=cfg.ddpm_steps, beta_schedule=cfg.beta_schedule,
+                                                     prediction_type=cfg.prediction_type)
+        self.n_steps = 0
+        self.cfg_scale = 1.3
+        self.kv = None
+        self._kv_t = None
+        self._llm_ws = None
+        self._llm_ws_rows = 0
+        self._graphs: Dict[str, int] = {}
+        self._graph_key = None
+        self.valid_ids: List[int] = []
+        self._w_valid = None
+        self._ids_dev = None
+        with torch.cuda.stream(self.stream):
+            self._alloc_ws()
+        self.set_steps(cfg.ddpm_infer)
+        self.stream.synchronize()
+
+    # ---------------------------------------------------------------------------------------------------------
+    @property
+    def sp(self) -> int:
+        return self.stream.cuda_stream
+
+    def _ck(self, rc, what):
+        L.check(rc, what)
+
+    def sync_in(self):
+        """Order the engine stream after whatever the caller enqueued on torch's current stream (inputs, weights)."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _alloc_ws(self):
+        lib = self.lib
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        self._dec_ws = torch.empty(lib.vv_convnet_ws_bytes(C.byref(self.w.dec), 1, 1), **u8)
+        self._sem_ws = torch.empty(lib.vv_convnet_ws_bytes(C.byref(self.w.sem), self.cfg.hop, 0), **u8)
+        self._ensure_llm_ws(2)
+
+    def _ensure_llm_ws(self, rows: int):
+        if rows > self._llm_ws_rows:
+            n = self.lib.vv_llm_ws_bytes(C.byref(self.w.llm), rows)
+            self._llm_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._llm_ws_rows = rows
+            self._drop_graphs()
+
+    def _drop_graphs(self):
+        for g in self._graphs.values():
+            self.lib.vv_graph_destroy(g)
+        self._graphs = {}
+
+    # ---------------------------------------------------------------------------------------------------------
+    def set_steps(self, n_steps: int):
+        """set_ddpm_inference_steps: schedule tables + the step-invariant t_embedder(t_i) table [n, D]."""
+        if n_steps == self.n_steps:
+            return
+        self.n_steps = n_steps
+        self.scheduler.set_timesteps(n_steps)
+        coefs = (L.DpmCoef * n_steps)()
+        for i, c in enumerate(self.scheduler.coefs):
+            coefs[i].alpha_s, coefs[i].sigma_s, coefs[i].cx, coefs[i].cd = c["alpha_s"], c["sigma_s"], c["cx"], c["cd"]
+            coefs[i].rinv, coefs[i].order = c["rinv"], c["order"]
+        self._coefs = coefs
+        D = self.cfg.head_hidden
+        with torch.cuda.stream(self.stream):
+            sin = timestep_sinusoid(self.scheduler.timesteps.numpy(), self.w.t_mlp0.shape[1], bf16_quirk=self.bf16_t_quirk).to(self.device)
+            t1 = torch.empty(n_steps, D, dtype=torch.float32, device=self.device)
+            self.temb = torch.empty(n_steps, D, dtype=torch.float32, device=self.device)
+            self.linear(sin, self.w.t_mlp0, t1)
+            self.linear(t1, self.w.t_mlp2, self.temb, pro=L.PRO_SILU)
+            self._head_ws = torch.empty(self.lib.vv_head_ws_bytes(C.byref(self.w.head), n_steps), dtype=torch.uint8, device=self.device)
+        self._drop_graphs()
+
+    def linear(self, x, w, out, pro=L.PRO_NONE, bias=None):
+        """thin vv_linear wrapper for [m,k] x [n,k]^T (host-side table building and tests)."""
+        a = L.LinArgs()
+        a.x, a.ldx, a.m = x.data_ptr(), x.stride(0), x.shape[0]
+        a.pro = pro
+        a.w, a.n, a.k = w.data_ptr(), w.shape[0], w.shape[1]
+        a.wdt = L.VV_F32 if w.dtype == torch.float32 else L.VV_BF16
+        a.bias = L.ptr(bias)
+        a.out, a.ldo = out.data_ptr(), out.stride(0)
+        self._ck(self.lib.vv_linear(C.byref(a), self.sp), "vv_linear")
+
+    # ---------------------------------------------------------------------------------------------------------
+    def begin_sequence(self, s_max: int, valid_ids: List[int]):
+        """Fresh utterance: KV cache sized for s_max tokens, conv states zeroed, constrained-vocabulary rows gathered."""
+        cfg = self.cfg
+        s_max = int(s_max)
+        with torch.cuda.stream(self.stream):
+            if self.kv is None or self.kv.s_max < s_max:
+                shape = (cfg.layers, 2, cfg.kv_heads, s_max, cfg.head_dim)
+                self._kv_t = (torch.zeros(shape, dtype=self.kv_dtype, device=self.device),
+                              torch.zeros(shape, dtype=self.kv_dtype, device=self.device))
+                kv = L.KV()
+                kv.k, kv.v = self._kv_t[0].data_ptr(), self._kv_t[1].data_ptr()
+                kv.kvdt = L.VV_F32 if self.kv_dtype == torch.float32 else L.VV_BF16
+                kv.layers, kv.rows, kv.kv_heads, kv.s_max, kv.head_dim = cfg.layers, 2, cfg.kv_heads, s_max, cfg.head_dim
+                self.kv = kv
+                self._drop_graphs()
+            ids = sorted(set(int(i) for i in valid_ids))
+            if ids != self.valid_ids:
+                self.valid_ids = ids
+                arr = (C.c_int * len(ids))(*ids)
+                self._w_valid = torch.empty(len(ids), cfg.hidden, dtype=self.dtype, device=self.device)
+                self._ck(self.lib.vv_gather_rows(self.w.lm_head.data_ptr(), self.w.wdt, cfg.hidden, arr, len(ids),
+                                                 self._w_valid.data_ptr(), self.sp), "vv_gather_rows")
+                self._ids_dev = torch.tensor(ids, dtype=torch.int32, device=self.device)
+                self._drop_graphs()
+            self.lens.zero_()
+            self.frame_ctr.zero_()
+            self.reset_speech_caches()
+
+    def reset_speech_caches(self):
+        """acoustic_cache.set_to_zero / semantic_cache.set_to_zero (modeling_vibevoice_inference.py:540-544)."""
+        self._ck(self.lib.vv_convnet_reset(C.byref(self.w.dec), self.sp), "vv_convnet_reset")
+        self._ck(self.lib.vv_convnet_reset(C.byref(self.w.sem), self.sp), "vv_convnet_reset")
+
+    # ---------------------------------------------------------------------------------------------------------
+    # component launch sequences (all asynchronous on self.stream)
+    # ---------------------------------------------------------------------------------------------------------
+    def llm_forward(self, x: torch.Tensor, lens: torch.Tensor, cache_rows: Optional[torch.Tensor], out: torch.Tensor):
+        R = x.shape[0]
+        self._ensure_llm_ws(R)
+        self._ck(self.lib.vv_llm_forward(C.byref(self.w.llm), C.byref(self.kv), x.data_ptr(), x.stride(0), R, lens.data_ptr(),
+                                         L.ptr(cache_rows), out.data_ptr(), out.stride(0), self._llm_ws.data_ptr(), self.sp),
+                 "vv_llm_forward")
+
+    def prefill(self, embeds: torch.Tensor, row: int = 0, pos0: int = 0, chunk: int = 1024) -> None:
+        """Prompt prefill on cache row `row`: embeds [L0, H] fp32 -> self.hidden2[row] = last hidden state; lens[row] = pos0+L0."""
+        L0 = embeds.shape[0]
+        with torch.cuda.stream(self.stream):
+            for c0 in range(0, L0, chunk):
+                c1 = min(L0, c0 + chunk)
+                n = c1 - c0
+                lens = torch.arange(pos0 + c0, pos0 + c1, dtype=torch.int32, device=self.device)
+                rows = torch.full((n,), row, dtype=torch.int32, device=self.device)
+                out = torch.empty(n, self.cfg.hidden, dtype=torch.float32, device=self.device)
+                self.llm_forward(embeds[c0:c1].contiguous(), lens, rows, out)
+            self.hidden2[row].copy_(out[-1])
+            self.lens[row] = pos0 + L0
+
+    def _select_token(self):
+        a = L.LinArgs()
+        nv = len(self.valid_ids)
+        a.x, a.ldx, a.m = self.hidden2.data_ptr(), self.cfg.hidden, 1
+        a.w, a.n, a.k, a.wdt = self._w_valid.data_ptr(), nv, self.cfg.hidden, self.w.wdt
+        a.out, a.ldo = self.logits.data_ptr(), nv
+        self._ck(self.lib.vv_linear(C.byref(a), self.sp), "lm_head")
+        self._ck(self.lib.vv_argmax_ids(self.logits.data_ptr(), nv, self._ids_dev.data_ptr(), self.token_dev.data_ptr(),
+                                        self.forced_dev.data_ptr(), self.sp), "vv_argmax_ids")
+
+    def _seq_A(self, tok_start, tok_diff):
+        """batch-2 decode step + token selection + device-side position bookkeeping."""
+        self._ck(self.lib.vv_llm_forward(C.byref(self.w.llm), C.byref(self.kv), self.x2.data_ptr(), self.cfg.hidden, 2,
+                                         self.lens.data_ptr(), None, self.hidden2.data_ptr(), self.cfg.hidden,
+                                         self._llm_ws.data_ptr(), self.sp), "vv_llm_forward")
+        self._select_token()
+        self._ck(self.lib.vv_advance_lens(self.lens.data_ptr(), self.token_dev.data_ptr(), tok_start, tok_diff,
+                                          self.frame_ctr.data_ptr(), self.sp), "vv_advance_lens")
+
+    def _seq_B(self, cfg_scale):
+        """speech_diffusion tail: sample latent, decode audio, re-encode semantics, build the next embedding."""
+        lib, w, cfg = self.lib, self.w, self.cfg
+        self._ck(lib.vv_head_sample(C.byref(w.head), self.hidden2.data_ptr(), cfg.hidden, self.noise_dev.data_ptr(),
+                                    self.temb.data_ptr(), self._coefs, self.n_steps, cfg_scale, self.latent.data_ptr(),
+                                    self._head_ws.data_ptr(), self.sp), "vv_head_sample")
+        self._ck(lib.vv_decoder_forward(C.byref(w.dec), self.latent.data_ptr(), 1, 1.0 / w.speech_scale, -w.speech_bias,
+                                        self.wav.data_ptr(), self._dec_ws.data_ptr(), self.sp), "vv_decoder_forward")
+        self._ck(lib.vv_encoder_forward(C.byref(w.sem), self.wav.data_ptr(), cfg.hop, self.sem.data_ptr(),
+                                        self._sem_ws.data_ptr(), self.sp), "vv_encoder_forward")
+        self._ck(lib.vv_connector_forward(C.byref(w.ac_conn), self.latent.data_ptr(), 1, self.x2.data_ptr(), 0,
+                                          self.conn_ws.data_ptr(), self.sp), "acoustic_connector")
+        self._ck(lib.vv_connector_forward(C.byref(w.sem_conn), self.sem.data_ptr(), 1, self.x2.data_ptr(), 1,
+                                          self.conn_ws.data_ptr(), self.sp), "semantic_connector")
+        self._ck(lib.vv_copy_rows(self.x2.data_ptr(), 0, self.x2.data_ptr() + 4 * cfg.hidden, cfg.hidden, 1, cfg.hidden, self.sp), "copy")
+
+    def _seq_C(self):
+        """next embedding = embed_tokens[token] for both rows (modeling_vibevoice_inference.py:567)."""
+        cfg = self.cfg
+        self._ck(self.lib.vv_embed_row(self.w.embed.data_ptr(), self.w.wdt, cfg.hidden, self.token_dev.data_ptr(), self.x2.data_ptr(), self.sp), "embed")
+        self._ck(self.lib.vv_copy_rows(self.x2.data_ptr(), 0, self.x2.data_ptr() + 4 * cfg.hidden, cfg.hidden, 1, cfg.hidden, self.sp), "copy")
+
+    def _run(self, name: str, fn, *args):
+        """Run a launch sequence, through a cached hipGraph when enabled."""
+        if not self.use_graphs:
+            fn(*args)
+            return
+        key = (name,) + tuple(args)
+        g = self._graphs.get(key)
+        if g is None:
+            self.stream.synchronize()
+            self._ck(self.lib.vv_graph_begin(self.sp), "graph begin")
+            try:
+                fn(*args)
+            finally:
+                ge = C.c_void_p()
+                rc = self.lib.vv_graph_end(self.sp, C.byref(ge))
+            self._ck(rc, "graph end")
+            g = ge.value
+            self._graphs[key] = g
+        self._ck(self.lib.vv_graph_launch(g, self.sp), "graph launch")
+
+    # ---------------------------------------------------------------------------------------------------------
+    # the three per-token phases used by generate()
+    # ---------------------------------------------------------------------------------------------------------
+    def step_decode(self, tok_start: int, tok_diff: int, forced: Optional[int] = None) -> int:
+        """Phase A + the frame's only host sync: returns the chosen token."""
+        with torch.cuda.stream(self.stream):
+            self.forced_host[0] = -1 if forced is None else int(forced)
+            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._run("A", self._seq_A, int(tok_start), int(tok_diff))
+            self.token_host.copy_(self.token_dev, non_blocking=True)
+        self.stream.synchronize()
+        return int(self.token_host[0])
+
+    def first_token(self, tok_start: int, tok_diff: int, forced: Optional[int] = None) -> int:
+        """Token selection right after prefill (hidden2[0] already holds the last prompt state)."""
+        with torch.cuda.stream(self.stream):
+            self.forced_host[0] = -1 if forced is None else int(forced)
+            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._select_token()
+            self.token_host.copy_(self.token_dev, non_blocking=True)
+        self.stream.synchronize()
+        return int(self.token_host[0])
+
+    def step_speech(self, noise: torch.Tensor):
+        """Phase B.  `noise` is the CPU fp32 [latent] row the reference would have drawn (modeling_vibevoice_inference.py:699)."""
+        self.noise_host.copy_(noise.reshape(-1)[: self.cfg.latent])
+        with torch.cuda.stream(self.stream):
+            self.noise_dev.copy_(self.noise_host, non_blocking=True)
+            self._run("B", self._seq_B, float(self.cfg_scale))
+
+    def step_embed(self):
+        with torch.cuda.stream(self.stream):
+            self._run("C", self._seq_C)
+
+    # ---------------------------------------------------------------------------------------------------------
+    # voice-prompt path (runs once per utterance)
+    # ---------------------------------------------------------------------------------------------------------
+    def acoustic_encode(self, wav: torch.Tensor) -> torch.Tensor:
+        """Whole-utterance (non-streaming) acoustic encoder: wav [T] -> mean latents [ceil(T/hop), vae_dim]."""
+        T = wav.shape[0]
+        F = (T + self.cfg.hop - 1) // self.cfg.hop
+        with torch.cuda.stream(self.stream):
+            x = wav.to(device=self.device, dtype=torch.float32).contiguous()
+            ws = torch.empty(self.lib.vv_convnet_ws_bytes(C.byref(self.w.ac_enc), T, 0), dtype=torch.uint8, device=self.device)
+            out = torch.empty(F, self.cfg.ac_dim, dtype=torch.float32, device=self.device)
+            self._ck(self.lib.vv_encoder_forward(C.byref(self.w.ac_enc), x.data_ptr(), T, out.data_ptr(), ws.data_ptr(), self.sp),
+                     "vv_encoder_forward")
+        return out
+
+    def connector(self, which: str, x: torch.Tensor) -> torch.Tensor:
+        c = self.w.ac_conn if which == "acoustic" else self.w.sem_conn
+        R = x.shape[0]
+        with torch.cuda.stream(self.stream):
+            x = x.to(device=self.device, dtype=torch.float32).contiguous()
+            out = torch.empty(R, self.cfg.hidden, dtype=torch.float32, device=self.device)
+            ws = torch.empty(R, self.cfg.hidden, dtype=torch.float32, device=self.device)
+            self._ck(self.lib.vv_connector_forward(C.byref(c), x.data_ptr(), R, out.data_ptr(), 0, ws.data_ptr(), self.sp), "connector")
+        return out
+
+    def embed_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            return self.w.embed[ids.to(self.device)].float()
+
+    def close(self):
+        self._drop_graphs()

@@ -1,0 +1,274 @@
+"""Host-side mirror of the reference's inference class on top of the MI355X engine.
+
+`VibeVoiceForConditionalGenerationInference` keeps the call surface `demo/inference_from_file.py` (and the Gradio
+apps) use — `from_pretrained(path, torch_dtype=, device_map=, attn_implementation=)`, `.eval()`,
+`.set_ddpm_inference_steps(num_steps=)`, `.generate(**processor_outputs, max_new_tokens=None, cfg_scale=,
+tokenizer=, generation_config={'do_sample': False}, verbose=, audio_streamer=, stop_check_fn=, ...)`,
+`.model.language_model.config._attn_implementation`, `.ddpm_inference_steps`, `.device`, `.model.noise_scheduler` —
+and returns the same `VibeVoiceGenerationOutput(sequences, speech_outputs, reach_max_step_sample)`
+(reference: vibevoice/modular/modeling_vibevoice_inference.py:38-51,68-147,326-693).
+The loop below restates :364-693 for one utterance per engine; a batch is served utterance by utterance
+(they are independent: SURVEY.md §8e).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .config import VVConfig
+from .engine import Engine
+from .synth import state_dict_shapes
+
+
+@dataclass
+class VibeVoiceGenerationOutput:
+    sequences: torch.LongTensor = None
+    speech_outputs: Optional[List[Optional[torch.Tensor]]] = None
+    reach_max_step_sample: Optional[torch.BoolTensor] = None
+
+
+def load_state_dict_from_dir(path: str) -> Dict[str, torch.Tensor]:
+    """HF sharded-safetensors checkpoint as the reference's converter writes it
+    (vibevoice/scripts/convert_nnscaler_checkpoint_to_transformers.py:116-123)."""
+    from safetensors.torch import load_file
+    idx = os.path.join(path, "model.safetensors.index.json")
+    files = []
+    if os.path.exists(idx):
+        with open(idx) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+    elif os.path.exists(os.path.join(path, "model.safetensors")):
+        files = ["model.safetensors"]
+    else:
+        raise FileNotFoundError(f"no model.safetensors[.index.json] under {path}")
+    sd: Dict[str, torch.Tensor] = {}
+    for fn in files:
+        sd.update(load_file(os.path.join(path, fn)))
+    return sd
+
+
+class VibeVoiceForConditionalGenerationInference:
+    def __init__(self, config: VVConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", torch_dtype=torch.bfloat16,
+                 attn_implementation: str = "hip_gfx950", use_graphs: bool = True):
+        missing = [k for k in state_dict_shapes(config) if k not in state_dict]
+        if missing:
+            raise KeyError(f"state dict is missing {len(missing)} tensors, e.g. {missing[:4]}")
+        self.config = config
+        self.dtype = torch_dtype
+        self.engine = Engine(config, state_dict, device=device, dtype=torch_dtype, use_graphs=use_graphs)
+        self.device = self.engine.device
+        self.ddpm_inference_steps = config.ddpm_infer
+        # attribute paths the reference's callers read
+        lm_cfg = SimpleNamespace(_attn_implementation=attn_implementation, hidden_size=config.hidden,
+                                 max_position_embeddings=config.max_pos)
+        self.model = SimpleNamespace(language_model=SimpleNamespace(config=lm_cfg), noise_scheduler=self.engine.scheduler)
+
+    # ---- construction ----------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.bfloat16, device_map=None,
+                        attn_implementation: Optional[str] = None, **kw):
+        """Load a local checkpoint directory (config.json + safetensors shards).  `attn_implementation` is accepted for
+        call compatibility; attention always runs on the hand-written gfx950 kernel."""
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            raise OSError(f"{path!r} is not a local checkpoint directory (this build has no hub access)")
+        cfg = VVConfig.from_pretrained(path)
+        device = device_map if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("auto", "cpu") else "cuda:0"
+        if str(device) == "cuda":
+            device = "cuda:0"
+        return cls(cfg, load_state_dict_from_dir(path), device=device, torch_dtype=torch_dtype,
+                   attn_implementation=attn_implementation or "hip_gfx950", use_graphs=kw.get("use_graphs", True))
+
+    @classmethod
+    def from_synthetic(cls, config: VVConfig, seed: int = 1234, device="cuda:0", torch_dtype=torch.bfloat16, numpy_weights=False, **kw):
+        """Random-init weights of the architecture (no checkpoints exist offline)."""
+        from .synth import synth_state_dict, synth_state_dict_torch
+        if numpy_weights:
+            sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(config, seed).items()}
+        else:
+            sd = synth_state_dict_torch(config, seed, device=device, dtype=torch_dtype)
+        return cls(config, sd, device=device, torch_dtype=torch_dtype, **kw)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def set_ddpm_inference_steps(self, num_steps=None):
+        self.ddpm_inference_steps = num_steps or self.config.ddpm_infer
+        self.engine.set_steps(self.ddpm_inference_steps)
+
+    @property
+    def noise_scheduler(self):
+        return self.engine.scheduler
+
+    # ---- voice-prompt prefill --------------------------------------------------------------------------------
+    def _process_speech_inputs(self, speech_tensors: torch.Tensor, speech_masks: torch.Tensor,
+                               std_noise: Optional[torch.Tensor] = None, eps_noise: Optional[torch.Tensor] = None):
+        """modeling_vibevoice_inference.py:149-163.  Returns (acoustic_features [S,F,64], connected [sum(mask), H])."""
+        eng, cfg = self.engine, self.config
+        S, Tmax = speech_tensors.shape
+        Fm = speech_masks.shape[1]
+        n_frames = speech_masks.sum(-1).tolist()
+        means = torch.zeros(S, Fm, cfg.ac_dim, dtype=torch.float32, device=self.device)
+        for i in range(S):
+            # causal encoder: frames < n_frames[i] only see samples < n_frames[i]*hop, so the zero tail of the padded batch
+            # row beyond that boundary never matters; when the boundary exceeds Tmax the reference pads features instead.
+            t_i = min(int(n_frames[i]) * cfg.hop, Tmax)
+            if t_i <= 0:
+                continue
+            m = eng.acoustic_encode(speech_tensors[i, :t_i])
+            means[i, : m.shape[0]] = m
+        with torch.cuda.stream(eng.stream):
+            if cfg.ac_std_dist == "gaussian":
+                if std_noise is None:
+                    std_noise = torch.randn(S, device=self.device, dtype=self.dtype)
+                    eps_noise = torch.randn_like(torch.empty(S, cfg.ac_dim, Fm, device=self.device, dtype=self.dtype).permute(0, 2, 1))
+                std = std_noise.to(self.device).float() * (cfg.ac_fix_std / 0.8)
+                lat = means + std[:, None, None] * eps_noise.to(self.device).float()
+            else:
+                lat = means
+            feats = (lat + eng.w.speech_bias) * eng.w.speech_scale
+            sel = feats[speech_masks.to(self.device)]
+        conn = eng.connector("acoustic", sel)
+        return feats, conn
+
+    # ---- generation --------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor = None, attention_mask: Optional[torch.Tensor] = None,
+                 speech_tensors: Optional[torch.Tensor] = None, speech_masks: Optional[torch.Tensor] = None,
+                 speech_input_mask: Optional[torch.Tensor] = None, tokenizer=None, generation_config=None,
+                 max_new_tokens: Optional[int] = None, cfg_scale: float = 1.0, audio_streamer=None,
+                 stop_check_fn: Optional[Callable[[], bool]] = None, return_speech: bool = True, **kwargs):
+        if tokenizer is None:
+            raise ValueError("generate() needs tokenizer= (for the speech_start/end/diffusion and eos ids)")
+        gen_cfg = dict(generation_config or {})
+        if gen_cfg.get("do_sample", False):
+            raise NotImplementedError("do_sample=True (temperature / top-p over the constrained vocabulary) is not built yet; "
+                                      "the reference's default path is greedy")
+        verbose = kwargs.get("verbose", False)
+        max_length_times = kwargs.get("max_length_times", 2)
+        refresh_negative = kwargs.get("refresh_negative", True)
+        if not refresh_negative:
+            raise NotImplementedError("refresh_negative=False is not built (every reference caller passes True / default)")
+        forced_tokens = kwargs.get("forced_tokens")          # extension: bench / fixtures drive the token schedule
+        noise = kwargs.get("noise")                          # extension: injected diffusion noise [F, latent]
+        speech_noise = kwargs.get("speech_noise")            # extension: (std_noise [S], eps_noise [S, F, 64])
+        self.engine.sync_in()
+        input_ids = torch.as_tensor(input_ids)
+        if input_ids.dim() == 1:
+            input_ids = input_ids[None]
+        B, Lp = input_ids.shape
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        special = dict(speech_start=tokenizer.speech_start_id, speech_end=tokenizer.speech_end_id,
+                       speech_diffusion=tokenizer.speech_diffusion_id, eos=tokenizer.eos_token_id,
+                       bos=getattr(tokenizer, "bos_token_id", None))
+        conn_all = None
+        if speech_tensors is not None and speech_masks is not None:
+            sn = speech_noise or (None, None)
+            _, conn_all = self._process_speech_inputs(torch.as_tensor(speech_tensors).float(), torch.as_tensor(speech_masks).bool(), *sn)
+        seqs, audios, reach = [], [], []
+        off = 0
+        for b in range(B):
+            keep = attention_mask[b].bool()
+            ids_b = input_ids[b][keep]                       # left padding carries no information (position_ids = cumsum(mask)-1)
+            sp_b = None
+            conn_b = None
+            if speech_input_mask is not None:
+                sp_b = torch.as_tensor(speech_input_mask)[b][keep].bool()
+                n_b = int(sp_b.sum())
+                if n_b and conn_all is not None:
+                    conn_b = conn_all[off: off + n_b]
+                    off += n_b
+            r = self._generate_one(ids_b, sp_b, conn_b, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
+                                   None if noise is None else torch.as_tensor(noise), audio_streamer, stop_check_fn, b, verbose)
+            seqs.append(torch.cat([input_ids[b][~keep], r["sequence"]]))
+            audios.append(r["audio"])
+            reach.append(r["reach_max"])
+        if audio_streamer is not None:
+            audio_streamer.end()
+        mx = max(s.shape[0] for s in seqs)
+        pad_id = getattr(tokenizer, "pad_id", None)
+        if pad_id is None:
+            pad_id = special["eos"]
+        seq_t = torch.full((B, mx), int(pad_id), dtype=torch.long)
+        for b, s in enumerate(seqs):
+            seq_t[b, : s.shape[0]] = s
+        return VibeVoiceGenerationOutput(sequences=seq_t, speech_outputs=audios if return_speech else None,
+                                         reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
+
+    def _generate_one(self, ids: torch.Tensor, sp_mask, conn, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
+                      noise, audio_streamer, stop_check_fn, sample_idx, verbose):
+        eng, cfg = self.engine, self.config
+        ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
+        valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
+        L0 = int(ids.shape[0])
+        max_length = cfg.max_pos if max_new_tokens is None else L0 + int(max_new_tokens)          # :370-371
+        max_steps = min(max_length - L0, int(max_length_times * L0))                            # :420
+        eng.cfg_scale = float(cfg_scale)
+        eng.begin_sequence(L0 + max(max_steps, 1) + 8, valid)
+        x0 = eng.embed_ids(ids)
+        if conn is not None:
+            with torch.cuda.stream(eng.stream):
+                x0[sp_mask.to(self.device)] = conn                                              # :221-224
+        seq = ids.tolist()
+        chunks: List[torch.Tensor] = []
+        reach_max = False
+        frame = 0
+        stream_idx = torch.tensor([sample_idx])
+        for step in range(max_steps):
+            if stop_check_fn is not None and stop_check_fn():                                  # :432-438
+                if verbose:
+                    print(f"Generation stopped externally at step {step + 1}")
+                if audio_streamer is not None:
+                    audio_streamer.end()
+                break
+            if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
+                break                                                                           # :441-445
+            if len(seq) >= max_length:                                                          # :452-457
+                reach_max = True
+                break
+            forced = forced_tokens[step] if (forced_tokens is not None and step < len(forced_tokens)) else None
+            if step == 0:
+                eng.prefill(x0, row=0, pos0=0)
+                tok = eng.first_token(ST, SD, forced)
+                if tok == SD:
+                    # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
+                    eng.prefill(eng.embed_ids(torch.tensor([ST])), row=1, pos0=0)
+            else:
+                tok = eng.step_decode(ST, SD, forced)                                           # :478-496 (+ speculative :581-583)
+            seq.append(tok)
+            if tok == EOS:                                                                      # :517-526
+                if verbose:
+                    print(f"Samples [{sample_idx}] reached EOS token at step {step + 1}.", flush=True)
+                if audio_streamer is not None:
+                    audio_streamer.end(stream_idx)
+                break
+            if tok == SE:                                                                       # :540-544
+                with torch.cuda.stream(eng.stream):
+                    eng.reset_speech_caches()
+            if tok == SD:                                                                       # :571-670
+                if noise is not None:
+                    nz = noise[frame]
+                else:
+                    nz = torch.randn(2, cfg.latent)[0]                                          # the reference's CPU draw (:699)
+                eng.step_speech(nz)
+                with torch.cuda.stream(eng.stream):
+                    chunk = eng.wav.clone()
+                chunks.append(chunk)
+                if audio_streamer is not None:
+                    audio_streamer.put(chunk[None, None], stream_idx)
+                frame += 1
+            else:
+                eng.step_embed()                                                                # :567
+        eng.stream.synchronize()
+        audio = torch.cat(chunks)[None] if chunks else None
+        return dict(sequence=torch.tensor(seq, dtype=torch.long), audio=audio, reach_max=reach_max)

@@ -1,0 +1,225 @@
+"""Device-resident weights in the layout the MI355X kernels stream, plus the ctypes descriptors that point at them.
+
+Input is a flat state dict with the reference's tensor names (`synth.state_dict_shapes`).
+Re-layouts done once at load time (HBM is 288 GB: we spend bytes to make every per-frame read a straight stream):
+  * q/k/v projection rows concatenated into one [q+2kv, H] matrix (+ one bias vector) -> one GEMV per layer;
+  * dense SConv1d weights [C_out, C_in, k] -> [C_out, k*C_in] (tap-major) so a conv is a GEMM over the
+    channels-last activation buffer read in place with overlapping rows;
+  * SConvTranspose1d weights [C_in, C_out, 2s] -> [(r, C_out), (j, C_in)] (j = 0 previous input, 1 current), bias
+    tiled over r: a transposed conv with k = 2s is one GEMM producing s output rows per input row;
+  * depthwise taps [C, 1, 7] -> [C, 7] fp32; every 1-D tensor fp32.
+Matrix weights are stored in `wdtype` (fp32 for graded parity, bf16 for the benchmark configs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import _lib as L
+from .config import VVConfig
+
+
+def _wdt(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return L.VV_F32
+    if dtype == torch.bfloat16:
+        return L.VV_BF16
+    raise ValueError(f"unsupported weight dtype {dtype}")
+
+
+class DeviceWeights:
+    """Owns every device tensor of the model and the C descriptors (vv_llm, vv_head, vv_convnet x3, vv_connector x2)."""
+
+    def __init__(self, cfg: VVConfig, sd: Dict[str, torch.Tensor], device, wdtype=torch.bfloat16, streaming_state=True):
+        self.cfg, self.device, self.wdtype = cfg, torch.device(device), wdtype
+        self.wdt = _wdt(wdtype)
+        self._keep: List[object] = []     # tensors / ctypes arrays that must outlive the descriptors
+        self._sd = sd
+        self.state_tensors: Dict[str, List[torch.Tensor]] = {"acoustic_dec": [], "semantic_enc": []}
+        self._build_llm()
+        self._build_head()
+        self.dec = self._build_convnet("model.acoustic_tokenizer.decoder.", decoder=True, filters=cfg.ac_dec_filters,
+                                       ratios=cfg.ac_ratios, depths_enc=cfg.ac_depths, dim=cfg.ac_dim, eps=cfg.ac_eps,
+                                       state_key="acoustic_dec" if streaming_state else None)
+        self.sem = self._build_convnet("model.semantic_tokenizer.encoder.", decoder=False, filters=cfg.sem_filters,
+                                       ratios=cfg.sem_ratios, depths_enc=cfg.sem_depths, dim=cfg.sem_dim, eps=cfg.sem_eps,
+                                       state_key="semantic_enc" if streaming_state else None)
+        self.ac_enc = self._build_convnet("model.acoustic_tokenizer.encoder.", decoder=False, filters=cfg.ac_filters,
+                                          ratios=cfg.ac_ratios, depths_enc=cfg.ac_depths, dim=cfg.ac_dim, eps=cfg.ac_eps,
+                                          state_key=None)     # voice prompts are encoded whole (non-streaming)
+        self.ac_conn = self._build_connector("model.acoustic_connector.", cfg.ac_dim)
+        self.sem_conn = self._build_connector("model.semantic_connector.", cfg.sem_dim)
+        self.speech_scale = float(sd["model.speech_scaling_factor"].float().item())
+        self.speech_bias = float(sd["model.speech_bias_factor"].float().item())
+        self._sd = None
+
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def _mat(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(device=self.device, dtype=self.wdtype).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _vec(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _zeros(self, *shape) -> torch.Tensor:
+        t = torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._keep if isinstance(t, torch.Tensor))
+
+    # ---- Qwen2 ---------------------------------------------------------------------------------------------------
+    def _build_llm(self):
+        cfg, sd = self.cfg, self._sd
+        p = "model.language_model."
+        self.embed = self._mat(sd[p + "embed_tokens.weight"])
+        self.lm_head = self.embed if (cfg.tie or "lm_head.weight" not in sd) else self._mat(sd["lm_head.weight"])
+        layers = (L.LlmLayer * cfg.layers)()
+        for l in range(cfg.layers):
+            q = f"{p}layers.{l}."
+            wqkv = self._mat(torch.cat([sd[q + "self_attn.q_proj.weight"], sd[q + "self_attn.k_proj.weight"],
+                                        sd[q + "self_attn.v_proj.weight"]], dim=0))
+            bqkv = self._vec(torch.cat([sd[q + "self_attn.q_proj.bias"], sd[q + "self_attn.k_proj.bias"],
+                                        sd[q + "self_attn.v_proj.bias"]], dim=0))
+            lay = layers[l]
+            lay.ln1 = L.ptr(self._vec(sd[q + "input_layernorm.weight"]))
+            lay.ln2 = L.ptr(self._vec(sd[q + "post_attention_layernorm.weight"]))
+            lay.wqkv, lay.bqkv = L.ptr(wqkv), L.ptr(bqkv)
+            lay.wo = L.ptr(self._mat(sd[q + "self_attn.o_proj.weight"]))
+            lay.wgate = L.ptr(self._mat(sd[q + "mlp.gate_proj.weight"]))
+            lay.wup = L.ptr(self._mat(sd[q + "mlp.up_proj.weight"]))
+            lay.wdown = L.ptr(self._mat(sd[q + "mlp.down_proj.weight"]))
+        # Qwen2RotaryEmbedding.compute_default_rope_parameters, same fp32 ops as the reference stack
+        inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float) / cfg.head_dim))
+        self.inv_freq = self._vec(inv_freq)
+        m = L.Llm()
+        m.wdt, m.hidden, m.inter, m.layers = self.wdt, cfg.hidden, cfg.inter, cfg.layers
+        m.heads, m.kv_heads, m.head_dim, m.rms_eps = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.rms_eps
+        m.inv_freq = L.ptr(self.inv_freq)
+        m.final_norm = L.ptr(self._vec(sd[p + "norm.weight"]))
+        m.layer = C.cast(layers, C.POINTER(L.LlmLayer))
+        self._keep.append(layers)
+        self.llm = m
+
+    # ---- diffusion head ------------------------------------------------------------------------------------------
+    def _build_head(self):
+        cfg, sd = self.cfg, self._sd
+        p = "model.prediction_head."
+        layers = (L.HeadLayer * cfg.head_layers)()
+        for l in range(cfg.head_layers):
+            q = f"{p}layers.{l}."
+            lay = layers[l]
+            lay.norm_w = L.ptr(self._vec(sd[q + "norm.weight"]))
+            lay.wgate = L.ptr(self._mat(sd[q + "ffn.gate_proj.weight"]))
+            lay.wup = L.ptr(self._mat(sd[q + "ffn.up_proj.weight"]))
+            lay.wdown = L.ptr(self._mat(sd[q + "ffn.down_proj.weight"]))
+            lay.adaln = L.ptr(self._mat(sd[q + "adaLN_modulation.1.weight"]))
+        h = L.Head()
+        h.wdt, h.D, h.ffn, h.layers, h.latent, h.cond_dim = self.wdt, cfg.head_hidden, cfg.head_ffn, cfg.head_layers, cfg.latent, cfg.hidden
+        h.eps = cfg.head_eps
+        h.noisy_proj = L.ptr(self._mat(sd[p + "noisy_images_proj.weight"]))
+        h.cond_proj = L.ptr(self._mat(sd[p + "cond_proj.weight"]))
+        h.final_adaln = L.ptr(self._mat(sd[p + "final_layer.adaLN_modulation.1.weight"]))
+        h.final_linear = L.ptr(self._mat(sd[p + "final_layer.linear.weight"]))
+        h.layer = C.cast(layers, C.POINTER(L.HeadLayer))
+        self._keep.append(layers)
+        self.head = h
+        self.t_mlp0 = self._mat(sd[p + "t_embedder.mlp.0.weight"])
+        self.t_mlp2 = self._mat(sd[p + "t_embedder.mlp.2.weight"])
+
+    # ---- conv tokenizers -----------------------------------------------------------------------------------------
+    def _conv(self, w: torch.Tensor, b: torch.Tensor, stride: int, transposed: bool, state_key) -> L.Conv:
+        c = L.Conv()
+        if transposed:
+            cin, cout, k = w.shape
+            s = stride
+            assert k == 2 * s, "SConvTranspose1d with k != 2*stride is not on the shipped path"
+            w4 = w.reshape(cin, cout, 2, s).flip(2)                     # [ci, co, j, r]: j=0 -> taps r+s (previous input)
+            wl = w4.permute(3, 1, 2, 0).reshape(s * cout, 2 * cin)      # [(r, co), (j, ci)]
+            bl = b.repeat(s)
+            ctx = 1
+        else:
+            cout, cin, k = w.shape
+            wl = w.permute(0, 2, 1).reshape(cout, k * cin)              # [co, (tap, ci)]
+            bl = b
+            ctx = k - stride
+        c.w, c.b = L.ptr(self._mat(wl)), L.ptr(self._vec(bl))
+        c.cin, c.cout, c.kk, c.stride, c.transposed = cin, cout, k, stride, int(transposed)
+        if state_key is not None and ctx > 0:
+            st = self._zeros(ctx, cin)
+            self.state_tensors[state_key].append(st)
+            c.state = L.ptr(st)
+        else:
+            c.state = None
+        return c
+
+    def _blocks(self, prefix: str, n: int, ch: int, state_key):
+        sd = self._sd
+        arr = (L.Block * max(n, 1))()
+        for j in range(n):
+            q = f"{prefix}{j}."
+            b = arr[j]
+            b.gamma = L.ptr(self._vec(sd[q + "gamma"]))
+            b.ffn_gamma = L.ptr(self._vec(sd[q + "ffn_gamma"]))
+            b.norm_w = L.ptr(self._vec(sd[q + "norm.weight"]))
+            b.ffn_norm_w = L.ptr(self._vec(sd[q + "ffn_norm.weight"]))
+            b.dw_w = L.ptr(self._vec(sd[q + "mixer.conv.conv.conv.weight"].reshape(ch, 7)))
+            b.dw_b = L.ptr(self._vec(sd[q + "mixer.conv.conv.conv.bias"]))
+            b.w1, b.b1 = L.ptr(self._mat(sd[q + "ffn.linear1.weight"])), L.ptr(self._vec(sd[q + "ffn.linear1.bias"]))
+            b.w2, b.b2 = L.ptr(self._mat(sd[q + "ffn.linear2.weight"])), L.ptr(self._vec(sd[q + "ffn.linear2.bias"]))
+            if state_key is not None:
+                h = self._zeros(6, ch)
+                self.state_tensors[state_key].append(h)
+                b.hist = L.ptr(h)
+            else:
+                b.hist = None
+        self._keep.append(arr)
+        return arr
+
+    def _build_convnet(self, prefix, decoder, filters, ratios, depths_enc, dim, eps, state_key) -> L.ConvNet:
+        sd = self._sd
+        n = len(depths_enc)
+        if n > L.VV_MAX_STAGES:
+            raise ValueError("too many tokenizer stages")
+        net = L.ConvNet()
+        net.wdt, net.n_stages, net.eps = self.wdt, n, eps
+        if decoder:
+            depths = list(reversed(depths_enc))
+            for i in range(n):
+                ch = filters * 2 ** (n - 1 - i)
+                if i == 0:
+                    q = prefix + "upsample_layers.0.0.conv.conv."
+                    net.sample[i] = self._conv(sd[q + "weight"], sd[q + "bias"], 1, False, state_key)
+                else:
+                    q = prefix + f"upsample_layers.{i}.0.convtr.convtr."
+                    net.sample[i] = self._conv(sd[q + "weight"], sd[q + "bias"], ratios[i - 1], True, state_key)
+                net.n_blocks[i] = depths[i]
+                arr = self._blocks(prefix + f"stages.{i}.", depths[i], ch, state_key)
+                net.blocks[i] = C.cast(arr, C.POINTER(L.Block))
+        else:
+            rr = list(reversed(ratios))
+            for i in range(n):
+                ch = filters * 2 ** i
+                q = prefix + f"downsample_layers.{i}.0.conv.conv."
+                net.sample[i] = self._conv(sd[q + "weight"], sd[q + "bias"], 1 if i == 0 else rr[i - 1], False, state_key)
+                net.n_blocks[i] = depths_enc[i]
+                arr = self._blocks(prefix + f"stages.{i}.", depths_enc[i], ch, state_key)
+                net.blocks[i] = C.cast(arr, C.POINTER(L.Block))
+        q = prefix + "head.conv.conv."
+        net.head = self._conv(sd[q + "weight"], sd[q + "bias"], 1, False, state_key)
+        return net
+
+    def _build_connector(self, prefix, din) -> L.Connector:
+        sd = self._sd
+        c = L.Connector()
+        c.wdt, c.din, c.hidden = self.wdt, din, self.cfg.hidden
+        c.fc1, c.b1 = L.ptr(self._mat(sd[prefix + "fc1.weight"])), L.ptr(self._vec(sd[prefix + "fc1.bias"]))
+        c.norm_w = L.ptr(self._vec(sd[prefix + "norm.weight"]))
+        c.fc2, c.b2 = L.ptr(self._mat(sd[prefix + "fc2.weight"])), L.ptr(self._vec(sd[prefix + "fc2.bias"]))
+        return c
