@@ -159,7 +159,8 @@ def test_scheduler_tables_match_reference(tiny_engine):
     for n in (10, 20, 50):
         tiny_engine.set_steps(n)
         assert tiny_engine.scheduler.timesteps.tolist() == g[f"timesteps_{n}"].tolist()
-        np.testing.assert_array_equal(tiny_engine.scheduler.sigmas.numpy(), g[f"sigmas_{n}"])
+        # fp32 host arithmetic (cumprod / sqrt) may differ by an ulp between the fixture box's CPU and this one
+        np.testing.assert_allclose(tiny_engine.scheduler.sigmas.numpy(), g[f"sigmas_{n}"], rtol=5e-7, atol=0)
 
 
 def test_head_forward_vs_reference(tiny_engine, lib):

@@ -114,6 +114,11 @@ class VibeVoiceForConditionalGenerationInference:
                                std_noise: Optional[torch.Tensor] = None, eps_noise: Optional[torch.Tensor] = None):
         """modeling_vibevoice_inference.py:149-163.  Returns (acoustic_features [S,F,64], connected [sum(mask), H])."""
         eng, cfg = self.engine, self.config
+        with torch.cuda.stream(eng.stream):      # every torch op of the prefill rides the engine stream
+            return self._process_speech_inputs_impl(speech_tensors, speech_masks, std_noise, eps_noise)
+
+    def _process_speech_inputs_impl(self, speech_tensors, speech_masks, std_noise, eps_noise):
+        eng, cfg = self.engine, self.config
         S, Tmax = speech_tensors.shape
         Fm = speech_masks.shape[1]
         n_frames = speech_masks.sum(-1).tolist()
@@ -147,6 +152,15 @@ class VibeVoiceForConditionalGenerationInference:
                  speech_input_mask: Optional[torch.Tensor] = None, tokenizer=None, generation_config=None,
                  max_new_tokens: Optional[int] = None, cfg_scale: float = 1.0, audio_streamer=None,
                  stop_check_fn: Optional[Callable[[], bool]] = None, return_speech: bool = True, **kwargs):
+        self.engine.sync_in()
+        with torch.cuda.stream(self.engine.stream):   # all torch glue (gathers, scatters, copies) rides the engine stream
+            out = self._generate(input_ids, attention_mask, speech_tensors, speech_masks, speech_input_mask, tokenizer,
+                                 generation_config, max_new_tokens, cfg_scale, audio_streamer, stop_check_fn, return_speech, **kwargs)
+        self.engine.stream.synchronize()
+        return out
+
+    def _generate(self, input_ids, attention_mask, speech_tensors, speech_masks, speech_input_mask, tokenizer, generation_config,
+                  max_new_tokens, cfg_scale, audio_streamer, stop_check_fn, return_speech, **kwargs):
         if tokenizer is None:
             raise ValueError("generate() needs tokenizer= (for the speech_start/end/diffusion and eos ids)")
         gen_cfg = dict(generation_config or {})
@@ -161,7 +175,6 @@ class VibeVoiceForConditionalGenerationInference:
         forced_tokens = kwargs.get("forced_tokens")          # extension: bench / fixtures drive the token schedule
         noise = kwargs.get("noise")                          # extension: injected diffusion noise [F, latent]
         speech_noise = kwargs.get("speech_noise")            # extension: (std_noise [S], eps_noise [S, F, 64])
-        self.engine.sync_in()
         input_ids = torch.as_tensor(input_ids)
         if input_ids.dim() == 1:
             input_ids = input_ids[None]
