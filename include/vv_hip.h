@@ -244,6 +244,14 @@ int vv_graph_end(vv_stream_t stream, void** graph_exec_out);
 int vv_graph_launch(void* graph_exec, vv_stream_t stream);
 int vv_graph_destroy(void* graph_exec);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-launch timing of vv_linear with HIP events recorded on the launch stream (eager mode only, never during
+ * graph capture).  vv_prof_begin arms it; vv_prof_end synchronises and aggregates by (m, n, k, dual, wdt).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct vv_prof_entry { int m, n, k, dual, wdt, count; double total_ms; } vv_prof_entry;
+int vv_prof_begin(int max_records);
+int vv_prof_end(vv_prof_entry* out, int max_out, int* n_out);
+
 /* struct sizes, for the ctypes mirror's self-check */
 size_t vv_sizeof(const char* struct_name);
 

@@ -78,7 +78,12 @@ class Connector(C.Structure):
                 ("fc2", vp), ("b2", vp)]
 
 
-_STRUCTS = dict(vv_lin_args=LinArgs, vv_kv=KV, vv_llm_layer=LlmLayer, vv_llm=Llm, vv_head_layer=HeadLayer, vv_head=Head,
+class ProfEntry(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("k", C.c_int), ("dual", C.c_int), ("wdt", C.c_int), ("count", C.c_int),
+                ("total_ms", C.c_double)]
+
+
+_STRUCTS = dict(vv_prof_entry=ProfEntry, vv_lin_args=LinArgs, vv_kv=KV, vv_llm_layer=LlmLayer, vv_llm=Llm, vv_head_layer=HeadLayer, vv_head=Head,
                 vv_dpm_coef=DpmCoef, vv_block=Block, vv_conv=Conv, vv_convnet=ConvNet, vv_connector=Connector)
 
 # name -> (restype, argtypes); every symbol include/vv_hip.h declares
@@ -114,6 +119,8 @@ PROTOTYPES = {
     "vv_graph_launch": (C.c_int, [vp, vp]),
     "vv_graph_destroy": (C.c_int, [vp]),
     "vv_sizeof": (C.c_size_t, [C.c_char_p]),
+    "vv_prof_begin": (C.c_int, [C.c_int]),
+    "vv_prof_end": (C.c_int, [C.POINTER(ProfEntry), C.c_int, C.POINTER(C.c_int)]),
 }
 
 

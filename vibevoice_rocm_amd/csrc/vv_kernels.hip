@@ -442,6 +442,51 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// optional per-launch timing of vv_linear with HIP events (eager mode only; used by bench.py's roofline leg)
+// ---------------------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int m, n, k, dual, wdt; };
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+size_t g_prof_cap = 0;
+}
+extern "C" int vv_prof_begin(int max_records) {
+  if (max_records <= 0) return vv_set_error(VV_E_ARG, "vv_prof_begin: max_records");
+  g_prof.clear();
+  g_prof.reserve(max_records);
+  g_prof_cap = (size_t)max_records;
+  g_prof_on = true;
+  return 0;
+}
+extern "C" int vv_prof_end(vv_prof_entry* out, int max_out, int* n_out) {
+  g_prof_on = false;
+  if (!out || !n_out) return vv_set_error(VV_E_ARG, "vv_prof_end: null");
+  int n = 0;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    if (e != hipSuccess) continue;
+    int j = 0;
+    for (; j < n; ++j)
+      if (out[j].m == r.m && out[j].n == r.n && out[j].k == r.k && out[j].dual == r.dual && out[j].wdt == r.wdt) break;
+    if (j == n) {
+      if (n >= max_out) continue;
+      out[n].m = r.m; out[n].n = r.n; out[n].k = r.k; out[n].dual = r.dual; out[n].wdt = r.wdt; out[n].count = 0; out[n].total_ms = 0.0;
+      ++n;
+    }
+    out[j].count += 1;
+    out[j].total_ms += ms;
+  }
+  g_prof.clear();
+  *n_out = n;
+  return 0;
+}
+
 extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   if (!a || !a->x || !a->w || !a->out) return vv_set_error(VV_E_ARG, "vv_linear: null pointer");
   if (a->m <= 0 || a->n <= 0 || a->k <= 0) return vv_set_error(VV_E_ARG, "vv_linear: bad shape m=%d n=%d k=%d", a->m, a->n, a->k);
@@ -451,10 +496,18 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   if (a->m > 8 && a->ldx == 0) return vv_set_error(VV_E_ARG, "vv_linear: broadcast rows (ldx=0) only for m<=8");
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  ProfRec pr;
+  const bool prof = g_prof_on && g_prof.size() < g_prof_cap;
+  if (prof) {
+    pr.m = a->m; pr.n = a->n; pr.k = a->k; pr.dual = a->w2 != nullptr; pr.wdt = a->wdt;
+    if (hipEventCreate(&pr.e0) != hipSuccess || hipEventCreate(&pr.e1) != hipSuccess) return vv_set_error(VV_E_HIP, "vv_linear: event create");
+    (void)hipEventRecord(pr.e0, s);
+  }
   if (a->wdt == VV_F32) rc = launch_linear<float>(*a, s);
   else if (a->wdt == VV_BF16) rc = launch_linear<bf16_t>(*a, s);
   else return vv_set_error(VV_E_ARG, "vv_linear: bad wdt %d", a->wdt);
   if (rc) return rc;
+  if (prof) { (void)hipEventRecord(pr.e1, s); g_prof.push_back(pr); }
   VV_CHECK_LAUNCH("vv_linear");
   return 0;
 }

@@ -400,7 +400,7 @@ extern "C" int vv_connector_forward(const vv_connector* c, const float* x, int R
 extern "C" size_t vv_sizeof(const char* name) {
   if (!name) return 0;
 #define S(t) if (!strcmp(name, #t)) return sizeof(t);
-  S(vv_lin_args) S(vv_kv) S(vv_llm_layer) S(vv_llm) S(vv_head_layer) S(vv_head) S(vv_dpm_coef) S(vv_block) S(vv_conv) S(vv_convnet) S(vv_connector)
+  S(vv_lin_args) S(vv_kv) S(vv_llm_layer) S(vv_llm) S(vv_head_layer) S(vv_head) S(vv_dpm_coef) S(vv_block) S(vv_conv) S(vv_convnet) S(vv_connector) S(vv_prof_entry)
 #undef S
   return 0;
 }
