@@ -102,6 +102,7 @@ def roofline_leg(model, wl, cfg_scale, frames=12):
     eng = model.engine
     was = eng.use_graphs
     eng.use_graphs = False
+    frames = min(frames, wl["noise"].shape[0])
     try:
         run_generate(model, wl, cfg_scale, n_frames=2, use_voice=False)            # warm
         L.check(lib.vv_prof_begin(400000), "vv_prof_begin")
@@ -126,9 +127,10 @@ def roofline_leg(model, wl, cfg_scale, frames=12):
 def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
     """The CPU oracle on a bounded sample of the same workload (kind: port)."""
     from oracle import vv_oracle as O
-    cores = len(os.sched_getaffinity(0))
+    # a 1-GPU box's CPU share is 16 cores even when the affinity mask lists the whole host: more threads only thrash
+    cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
-    eng = model.engine
+    log(f"cpu baseline: {cores} threads, copying weights to host")
     sd = {}
     # the oracle computes in fp32 on the bf16-rounded weights the GPU path streams
     from vibevoice_rocm_amd.synth import synth_state_dict_torch
@@ -142,6 +144,7 @@ def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
     noise = torch.randn(frames, cfg.latent, generator=g)
     forced = [special["speech_diffusion"]] * frames + [special["speech_end"], special["eos"]]
     ocfg = cfg.as_dict()
+    log("cpu baseline: weights on host, running the oracle")
     t0 = time.time()
     res = O.generate(sd, ocfg, ids, None, None, special, noise, cfg_scale=cfg_scale, n_steps=n_steps, forced_tokens=forced)
     dt = time.time() - t0
@@ -149,6 +152,13 @@ def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
     return dict(value=audio_s / dt, unit="audio-sec/s", cores=cores, kind="port",
                 sample=f"oracle/vv_oracle.py generate(): {prompt + 1}-token prompt (no voice prompt), {frames} frames, CFG={cfg_scale}, "
                        f"{n_steps} steps, fp32 torch-CPU on the bf16-rounded weights, {dt:.1f} s wall")
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -191,7 +201,9 @@ def main():
     sd = synth_state_dict_torch(cfg, 1234, device=device, dtype=dtype) if rank == 0 else None
     if world > 1:
         sd = vd.broadcast_state_dict(sd, cfg, dtype, device, src=0)
+    log("weights ready")
     model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
+    log(f"engine ready ({model.engine.w.nbytes() / 1e9:.2f} GB resident)")
     model._bench_sd = sd if (rank == 0 and not args.no_cpu_baseline) else None
     if model._bench_sd is None:
         del sd
@@ -207,8 +219,11 @@ def main():
         torch.cuda.synchronize()
 
     out = None
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         out = run_generate(model, wl, args.cfg_scale)
+        torch.cuda.synchronize()
+        log(f"warmup {i}: {time.perf_counter() - tw:.2f} s")
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -226,6 +241,7 @@ def main():
     assert n_samples == args.frames * cfg.hop, (n_samples, args.frames)
     assert bool(torch.isfinite(out.speech_outputs[0]).all())
     value = world * args.steps * audio_s / dt
+    log(f"timed: {args.steps} steps in {dt:.2f} s -> {value:.2f} audio-sec/s")
 
     result = None
     if rank == 0:
@@ -248,6 +264,7 @@ def main():
         }
     if rank == 0 and not args.no_roofline:
         ents = roofline_leg(model, wl, args.cfg_scale)
+        log("roofline leg done")
         top = ents[0]
         traffic = None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -264,6 +281,7 @@ def main():
         result["kernels"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in e.items()} for e in ents[:8]]
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_leg(model, cfg, args.cfg_scale, args.ddpm_steps)
+        log("cpu baseline done")
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
