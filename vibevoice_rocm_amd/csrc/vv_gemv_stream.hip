@@ -1,0 +1,269 @@
+// vv_gemv_stream.hip — the batch-1/2 weight-streaming GEMV of the per-frame path (bf16 weights, M <= 4 rows).
+//
+// Roofline: HBM.  Every weight byte is read once per call with non-temporal 16-byte loads straight into VGPRs
+// (no LDS round trip: nothing is shared between waves), the activation slice each lane needs lives in registers
+// for the whole kernel (prologue = RMSNorm / adaLN modulate / SiLU fused, computed once per wave), and the
+// workgroups are persistent: each wave walks its row groups with the next group's loads already in flight while
+// it reduces the current one (register double buffering), so the memory pipe never drains between rows.
+//   KSPLIT == 1  a wave owns RW whole weight rows per step               (K <= 2560)
+//   KSPLIT == 4  the block's 4 waves split K (interleaved 512-element units) and combine through LDS (long K)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vv_hip.h"
+#include "vv_common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&o)[8]) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v, float v2) {
+  if (a.bias) v += a.bias[n];
+  if (a.act == VV_ACT_GELU) v = gelu1(v);
+  else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
+  if (a.gate) v *= a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n];
+  if (a.res) v += a.res[(int64_t)m * a.ldres + n];
+  a.out[(int64_t)m * a.ldo + n] = v;
+}
+
+constexpr int RW = 2;   // weight rows per wave step
+
+template <int M, bool DUAL, int KSPLIT, int KU>
+__global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
+  __shared__ float red[4 * M];
+  __shared__ float part[2][4][RW * M * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.k, N = a.n, mr = a.m;          // mr <= M real rows
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
+  const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
+
+  // ---- this lane's k offsets and activation fragment (kept in registers for the whole kernel) -------------------
+  int koff[KU];
+  bool kval[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    const int unit = (KSPLIT == 1) ? u : (wave + 4 * u);
+    koff[u] = unit * 512 + lane * 8;
+    kval[u] = koff[u] < K;
+    if (!kval[u]) koff[u] = 0;                    // any valid address; the activation there is forced to 0
+  }
+  // the first row group's weight loads are issued before the activation prologue so both latencies overlap
+  const int gstride = (KSPLIT == 1) ? gridDim.x * 4 : gridDim.x;
+  int g = (KSPLIT == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+  u32x4 cur[RW][KU], cur2[DUAL ? RW : 1][KU];
+  u32x4 nxt[RW][KU], nxt2[DUAL ? RW : 1][KU];
+  auto issue = [&](u32x4 (&b)[RW][KU], u32x4 (&b2)[DUAL ? RW : 1][KU], int grp) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int n = min(grp * RW + r, N - 1);
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        b[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + koff[u]));
+        if (DUAL) b2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W2 + (int64_t)n * K + koff[u]));
+      }
+    }
+  };
+  if (g < n_groups) issue(cur, cur2, g);
+  float xr[M][KU][8];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float* xrow = a.x + (int64_t)(m < mr ? m : mr - 1) * a.ldx;
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (kval[u]) {
+        const float4 p = *reinterpret_cast<const float4*>(xrow + koff[u]);
+        const float4 q = *reinterpret_cast<const float4*>(xrow + koff[u] + 4);
+        xr[m][u][0] = p.x; xr[m][u][1] = p.y; xr[m][u][2] = p.z; xr[m][u][3] = p.w;
+        xr[m][u][4] = q.x; xr[m][u][5] = q.y; xr[m][u][6] = q.z; xr[m][u][7] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[m][u][j] = 0.f;
+      }
+      if (a.pro == VV_PRO_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[m][u][j] = silu1(xr[m][u][j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss = fmaf(xr[m][u][j], xr[m][u][j], ss);
+    }
+    if (a.pro == VV_PRO_RMSNORM) {
+      ss = wsum(ss);                               // KSPLIT == 1: every wave holds the whole row
+      if (KSPLIT != 1) {
+        if (lane == 0) red[wave * M + m] = ss;
+        __syncthreads();
+        ss = red[m] + red[M + m] + red[2 * M + m] + red[3 * M + m];
+      }
+      const float rstd = rsqrtf(ss / (float)K + a.eps);
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        if (!kval[u]) continue;
+        float nw[8], sh[8], sc[8];
+        if (a.norm_w) {
+          const float4 p = *reinterpret_cast<const float4*>(a.norm_w + koff[u]);
+          const float4 q = *reinterpret_cast<const float4*>(a.norm_w + koff[u] + 4);
+          nw[0] = p.x; nw[1] = p.y; nw[2] = p.z; nw[3] = p.w; nw[4] = q.x; nw[5] = q.y; nw[6] = q.z; nw[7] = q.w;
+        }
+        if (a.mod_scale) {
+          const int64_t mo = (int64_t)(m < mr ? m : mr - 1) * a.ld_mod + koff[u];
+          const float4 s0 = *reinterpret_cast<const float4*>(a.mod_shift + mo), s1 = *reinterpret_cast<const float4*>(a.mod_shift + mo + 4);
+          const float4 c0 = *reinterpret_cast<const float4*>(a.mod_scale + mo), c1 = *reinterpret_cast<const float4*>(a.mod_scale + mo + 4);
+          sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w; sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
+          sc[0] = c0.x; sc[1] = c0.y; sc[2] = c0.z; sc[3] = c0.w; sc[4] = c1.x; sc[5] = c1.y; sc[6] = c1.z; sc[7] = c1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = xr[m][u][j] * rstd;
+          if (a.norm_w) v *= nw[j];
+          if (a.mod_scale) v = v * (1.0f + sc[j]) + sh[j];
+          xr[m][u][j] = v;
+        }
+      }
+    }
+  }
+
+  // ---- stream the weight rows ------------------------------------------------------------------------------------
+  int parity = 0;
+  while (g < n_groups) {
+    const int gn = g + gstride;
+    if (gn < n_groups) issue(nxt, nxt2, gn);      // next group's bytes are in flight while this one is reduced
+    float acc[RW][M], acc2[DUAL ? RW : 1][M];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int m = 0; m < M; ++m) { acc[r][m] = 0.f; if (DUAL) acc2[r][m] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        float w[8], w2[8];
+        unpack8(cur[r][u], w);
+        if (DUAL) unpack8(cur2[r][u], w2);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[r][m] = fmaf(w[j], xr[m][u][j], acc[r][m]);
+            if (DUAL) acc2[r][m] = fmaf(w2[j], xr[m][u][j], acc2[r][m]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int m = 0; m < M; ++m) { acc[r][m] = wsum(acc[r][m]); if (DUAL) acc2[r][m] = wsum(acc2[r][m]); }
+    if (KSPLIT == 1) {
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int n = g * RW + r;
+          if (n < N) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) if (m < mr) epi(a, m, n, acc[r][m], DUAL ? acc2[r][m] : 0.f);
+          }
+        }
+      }
+    } else {
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int m = 0; m < M; ++m) {
+            part[parity][wave][(r * M + m) * 2] = acc[r][m];
+            part[parity][wave][(r * M + m) * 2 + 1] = DUAL ? acc2[r][m] : 0.f;
+          }
+      }
+      __syncthreads();                             // g is block-uniform when KSPLIT != 1
+      if (tid < RW * M) {
+        const int r = tid / M, m = tid - r * M;
+        const int n = g * RW + r;
+        if (n < N && m < mr) {
+          float s = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) { s += part[parity][w4][tid * 2]; s2 += part[parity][w4][tid * 2 + 1]; }
+          epi(a, m, n, s, s2);
+        }
+      }
+      parity ^= 1;                                 // ping-pong: one barrier per group is enough
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) { cur[r][u] = nxt[r][u]; if (DUAL) cur2[r][u] = nxt2[r][u]; }
+    g = gn;
+  }
+}
+
+template <int M, bool DUAL, int KSPLIT, int KU>
+void launch_one(const vv_lin_args& a, hipStream_t s) {
+  // persistent grid: as many blocks as can be co-resident (2 per CU for the register-heavy dual kernel, 4 otherwise),
+  // sized so every wave walks the same number of row groups (no half-empty last round)
+  const int n_groups = (a.n + RW - 1) / RW;
+  const int work = (KSPLIT == 1) ? (n_groups + 3) / 4 : n_groups;       // blocks if each wave did exactly one group
+  const int resident = DUAL ? 512 : 1024;
+  const int rounds = (work + resident - 1) / resident;
+  int blocks = (work + rounds - 1) / rounds;
+  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU>), dim3(blocks), dim3(256), 0, s, a, n_groups);
+}
+
+template <int M, bool DUAL>
+bool launch_ku(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
+  if (ksplit == 1) {
+    switch (ku) {
+      case 1: launch_one<M, DUAL, 1, 1>(a, s); return true;
+      case 2: launch_one<M, DUAL, 1, 2>(a, s); return true;
+      case 3: launch_one<M, DUAL, 1, 3>(a, s); return true;
+      case 4: launch_one<M, DUAL, 1, 4>(a, s); return true;
+      case 5: launch_one<M, DUAL, 1, 5>(a, s); return true;
+    }
+    return false;
+  }
+  if (DUAL) return false;
+  if constexpr (!DUAL) {
+    switch (ku) {
+      case 2: launch_one<M, false, 4, 2>(a, s); return true;
+      case 3: launch_one<M, false, 4, 3>(a, s); return true;
+      case 4: launch_one<M, false, 4, 4>(a, s); return true;
+      case 5: launch_one<M, false, 4, 5>(a, s); return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+// returns 1 when the call was launched here, 0 when the shape/alignment is not covered (caller falls back)
+int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {
+  if (a.wdt != VV_BF16 || a.m > 4 || a.k % 8) return 0;
+  if ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16) || (uintptr_t)a.x % 16) return 0;
+  if (a.m > 1 && a.ldx % 4) return 0;
+  if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
+  if (a.mod_scale && ((uintptr_t)a.mod_scale % 16 || (uintptr_t)a.mod_shift % 16 || a.ld_mod % 4)) return 0;
+  const int units = (a.k + 511) / 512;
+  int ksplit = 1, ku = units;
+  if (units > 5) { ksplit = 4; ku = (units + 3) / 4; }
+  if (ku > 5 || (ksplit == 4 && ku < 2)) return 0;
+  const bool dual = a.w2 != nullptr;
+  bool ok;
+  if (a.m == 1) ok = dual ? launch_ku<1, true>(a, s, ksplit, ku) : launch_ku<1, false>(a, s, ksplit, ku);
+  else if (a.m == 2) ok = dual ? launch_ku<2, true>(a, s, ksplit, ku) : launch_ku<2, false>(a, s, ksplit, ku);
+  else ok = dual ? launch_ku<4, true>(a, s, ksplit, ku) : launch_ku<4, false>(a, s, ksplit, ku);
+  return ok ? 1 : 0;
+}

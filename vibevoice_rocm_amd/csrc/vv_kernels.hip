@@ -269,50 +269,59 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_generic_kernel(const vv_lin
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GEMM (M > 8): 64x64 output tile per 256-thread block, 4x4 micro-tile per thread, K stepped by 16 through LDS.
+// GEMM (M > 8): TMT x TNT output tile per 256-thread block (64x64 with a 4x4 micro-tile, or 32x32 with 2x2 when the
+// problem is too small to fill the chip with big tiles), K stepped by 16 through LDS with the next K-slab's global
+// loads already in flight in registers while the current one is multiplied.
 // A rows may overlap (ldx < k): that is how dense Conv1d / ConvTranspose1d read their im2col view in place.
 // ---------------------------------------------------------------------------------------------------------------
-#define TM 64
-#define TN 64
 #define TK 16
 
-template <typename WT, bool DUAL, bool VEC>
+template <typename WT, bool DUAL, bool VEC, int TMT, int TNT>
 __global__ __launch_bounds__(256) void gemm_kernel(const vv_lin_args a) {
-  __shared__ __attribute__((aligned(16))) float As[TK][TM + 4];
-  __shared__ __attribute__((aligned(16))) float Ws[TK][TN + 4];
-  __shared__ __attribute__((aligned(16))) float Ws2[DUAL ? TK : 1][TN + 4];
-  __shared__ float rs[TM];
+  constexpr int MI = TMT / 16, NJ = TNT / 16;
+  constexpr bool BOTH = (TMT == 64);            // 64x64: every thread stages one A slot and one W slot; 32x32: half/half
+  __shared__ __attribute__((aligned(16))) float As[TK][TMT + 4];
+  __shared__ __attribute__((aligned(16))) float Ws[TK][TNT + 4];
+  __shared__ __attribute__((aligned(16))) float Ws2[DUAL ? TK : 1][TNT + 4];
+  __shared__ float rs[TMT];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+  const int m0 = blockIdx.y * TMT, n0 = blockIdx.x * TNT;
   const int M = a.m, N = a.n, K = a.k;
   const WT* __restrict__ W = reinterpret_cast<const WT*>(a.w);
   const WT* __restrict__ W2 = reinterpret_cast<const WT*>(a.w2);
 
   if (a.pro == VV_PRO_RMSNORM) {
-    const int r = tid >> 2, q = tid & 3;
+    constexpr int TPR = 256 / TMT;              // threads per row: 4 or 8
+    const int r = tid / TPR, q = tid % TPR;
     float s = 0.f;
     if (m0 + r < M) {
       const float* xr = a.x + (int64_t)(m0 + r) * a.ldx;
-      for (int k = q; k < K; k += 4) { const float v = xr[k]; s += v * v; }
+      for (int k = q; k < K; k += TPR) { const float v = xr[k]; s += v * v; }
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o);
     if (q == 0) rs[r] = rsqrtf(s / (float)K + a.eps);
     __syncthreads();
   }
 
-  float acc[4][4], acc2[DUAL ? 4 : 1][4];
+  float acc[MI][NJ], acc2[DUAL ? MI : 1][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { acc[i][j] = 0.f; if (DUAL) acc2[i][j] = 0.f; }
+    for (int j = 0; j < NJ; ++j) { acc[i][j] = 0.f; if (DUAL) acc2[i][j] = 0.f; }
 
-  const int lr = tid >> 2, lk = (tid & 3) * 4;   // this thread stages row lr, k offsets lk..lk+3 of both tiles
-  for (int k0 = 0; k0 < K; k0 += TK) {
-    float av[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f}, wv2[4] = {0.f, 0.f, 0.f, 0.f};
+  // staging roles
+  const bool doA = BOTH || tid < 128;
+  const bool doW = BOTH || tid >= 128;
+  const int st = BOTH ? tid : (tid & 127);
+  const int lr = st >> 2, lk = (st & 3) * 4;
+
+  auto load_slab = [&](int k0, float (&av)[4], float (&wv)[4], float (&wv2)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { av[i] = 0.f; wv[i] = 0.f; wv2[i] = 0.f; }
     const int kb = k0 + lk;
-    if (m0 + lr < M) {
+    if (doA && m0 + lr < M) {
       const float* xr = a.x + (int64_t)(m0 + lr) * a.ldx + kb;
       if (VEC && kb + 3 < K) {
         const float4 v = *reinterpret_cast<const float4*>(xr);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vv_lin_args a) {
         for (int i = 0; i < 4; ++i) av[i] = silu_f(av[i]);
       }
     }
-    if (n0 + lr < N) {
+    if (doW && n0 + lr < N) {
       const WT* wr = W + (int64_t)(n0 + lr) * K + kb;
       if (VEC && kb + 3 < K) {
         WL<WT>::load4(wr, wv);
@@ -348,31 +357,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vv_lin_args a) {
         }
       }
     }
-    __syncthreads();
+  };
+  auto store_slab = [&](const float (&av)[4], const float (&wv)[4], const float (&wv2)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { As[lk + i][lr] = av[i]; Ws[lk + i][lr] = wv[i]; if (DUAL) Ws2[lk + i][lr] = wv2[i]; }
-    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      if (doA) As[lk + i][lr] = av[i];
+      if (doW) { Ws[lk + i][lr] = wv[i]; if (DUAL) Ws2[lk + i][lr] = wv2[i]; }
+    }
+  };
+
+  float av[4], wv[4], wv2[4];
+  load_slab(0, av, wv, wv2);
+  store_slab(av, wv, wv2);
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += TK) {
+    const bool more = k0 + TK < K;
+    if (more) load_slab(k0 + TK, av, wv, wv2);          // in flight while this slab is multiplied
 #pragma unroll
     for (int kk = 0; kk < TK; ++kk) {
-      const float4 av4 = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-      const float4 bv4 = *reinterpret_cast<const float4*>(&Ws[kk][tx * 4]);
-      const float ar[4] = {av4.x, av4.y, av4.z, av4.w};
-      const float br[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
-      float br2[4] = {0.f, 0.f, 0.f, 0.f};
-      if (DUAL) { const float4 c = *reinterpret_cast<const float4*>(&Ws2[kk][tx * 4]); br2[0] = c.x; br2[1] = c.y; br2[2] = c.z; br2[3] = c.w; }
+      float ar[MI], br[NJ], br2[NJ];
+      if constexpr (MI == 4) { const float4 v = *reinterpret_cast<const float4*>(&As[kk][ty * 4]); ar[0] = v.x; ar[1] = v.y; ar[MI - 2] = v.z; ar[MI - 1] = v.w; }
+      else { const float2 v = *reinterpret_cast<const float2*>(&As[kk][ty * 2]); ar[0] = v.x; ar[1] = v.y; }
+      if constexpr (NJ == 4) { const float4 v = *reinterpret_cast<const float4*>(&Ws[kk][tx * 4]); br[0] = v.x; br[1] = v.y; br[NJ - 2] = v.z; br[NJ - 1] = v.w; }
+      else { const float2 v = *reinterpret_cast<const float2*>(&Ws[kk][tx * 2]); br[0] = v.x; br[1] = v.y; }
+      if (DUAL) {
+        if constexpr (NJ == 4) { const float4 v = *reinterpret_cast<const float4*>(&Ws2[kk][tx * 4]); br2[0] = v.x; br2[1] = v.y; br2[NJ - 2] = v.z; br2[NJ - 1] = v.w; }
+        else { const float2 v = *reinterpret_cast<const float2*>(&Ws2[kk][tx * 2]); br2[0] = v.x; br2[1] = v.y; }
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[i][j] = fmaf(ar[i], br[j], acc[i][j]); if (DUAL) acc2[i][j] = fmaf(ar[i], br2[j], acc2[i][j]); }
+        for (int j = 0; j < NJ; ++j) { acc[i][j] = fmaf(ar[i], br[j], acc[i][j]); if (DUAL) acc2[i][j] = fmaf(ar[i], br2[j], acc2[i][j]); }
+    }
+    if (more) {
+      __syncthreads();
+      store_slab(av, wv, wv2);
+      __syncthreads();
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + ty * MI + i;
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + tx * NJ + j;
       if (n < N) lin_epilogue(a, m, n, acc[i][j], DUAL ? acc2[i][j] : 0.f);
     }
   }
@@ -422,6 +451,22 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const size_t wsz = sizeof(WT);
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
   if (a.m <= 8) {
+    if (a.m <= 4 && vv_launch_gemv_stream(a, s)) return 0;      // bf16 weight-streaming fast path
+    if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
+      // 5..8 rows: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
+      vv_lin_args lo = a, hi = a;
+      lo.m = 4;
+      hi.m = a.m - 4;
+      hi.x = a.x + 4 * a.ldx;
+      hi.out = a.out + 4 * a.ldo;
+      if (a.res) hi.res = a.res + 4 * a.ldres;
+      if (a.gate && a.gate_ld) hi.gate = a.gate + 4 * a.gate_ld;
+      if (a.mod_scale) { hi.mod_scale = a.mod_scale + 4 * a.ld_mod; hi.mod_shift = a.mod_shift + 4 * a.ld_mod; }
+      if (vv_launch_gemv_stream(lo, s)) {
+        if (vv_launch_gemv_stream(hi, s)) return 0;
+        return vv_set_error(VV_E_HIP, "vv_linear: split GEMV second half not covered");
+      }
+    }
     const bool fast = (a.k % 8 == 0) && w_al16 && ((a.k * wsz) % 16 == 0);
     if (fast) return dual ? launch_gemv_m<WT, true>(a, s) : launch_gemv_m<WT, false>(a, s);
     int blocks = (a.n + 3) / 4;
@@ -430,15 +475,19 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
     return 0;
   }
   const bool vec = (a.k % 4 == 0) && (a.ldx % 4 == 0) && ((uintptr_t)a.x % 16 == 0) && w_al16;
-  dim3 grid((a.n + TN - 1) / TN, (a.m + TM - 1) / TM);
+  const long big_tiles = (long)((a.n + 63) / 64) * ((a.m + 63) / 64);
+  const bool small = big_tiles < 192;              // too few 64x64 tiles to fill 256 CUs: use 32x32 tiles
+  const int tm = small ? 32 : 64;
+  dim3 grid((a.n + tm - 1) / tm, (a.m + tm - 1) / tm);
   if (grid.y > 65535u) return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: m=%d rows exceed one launch (split the call)", a.m);
-  if (dual) {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<WT, true, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<WT, true, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<WT, false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<WT, false, false>), grid, dim3(256), 0, s, a);
-  }
+#define VV_GEMM_LAUNCH(D, V)                                                                                  \
+  do {                                                                                                        \
+    if (small) hipLaunchKernelGGL((gemm_kernel<WT, D, V, 32, 32>), grid, dim3(256), 0, s, a);                 \
+    else hipLaunchKernelGGL((gemm_kernel<WT, D, V, 64, 64>), grid, dim3(256), 0, s, a);                       \
+  } while (0)
+  if (dual) { if (vec) VV_GEMM_LAUNCH(true, true); else VV_GEMM_LAUNCH(true, false); }
+  else { if (vec) VV_GEMM_LAUNCH(false, true); else VV_GEMM_LAUNCH(false, false); }
+#undef VV_GEMM_LAUNCH
   return 0;
 }
 
@@ -669,53 +718,58 @@ extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C,
                                                           const float* norm_w, float eps, const float* dw_w, const float* dw_b,
-                                                          const float* gamma, float* hist, int TR) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [TR + 6][C] normalised rows
+                                                          const float* gamma, float* hist, int TR, int CS) {
+  // grid = (row tiles, channel slices).  A block owns rows [t0, t0+tr) x channels [c0, c0+cs); the per-row RMS statistic
+  // needs the whole row, so it is recomputed by every channel slice (only wide-C / short-T stages have > 1 slice).
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [TR + 6][CS] normalised rows of this slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t0 = blockIdx.x * TR;
   const int tr = min(TR, T - t0);
+  const int c0 = blockIdx.y * CS;
+  const int cs = min(CS, C - c0);
+  auto row_rstd = [&](const float* xr) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
+    s = wave_sum(s);
+    return rsqrtf(s / (float)C + eps);
+  };
   // rows t0-6 .. t0+tr-1 -> sm rows 0 .. tr+5
   for (int rr = wave; rr < tr + 6; rr += 4) {
     const int t = t0 - 6 + rr;
-    float* dst = sm + (int64_t)rr * C;
+    float* dst = sm + (int64_t)rr * CS;
     if (t < 0) {
-      for (int c = lane; c < C; c += 64) dst[c] = hist ? hist[(int64_t)(6 + t) * C + c] : 0.f;   // t in [-6,-1] -> hist row 6+t
+      for (int c = lane; c < cs; c += 64) dst[c] = hist ? hist[(int64_t)(6 + t) * C + c0 + c] : 0.f;   // t in [-6,-1] -> hist row 6+t
     } else {
       const float* xr = x + (int64_t)t * C;
-      float s = 0.f;
-      for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
-      s = wave_sum(s);
-      const float rstd = rsqrtf(s / (float)C + eps);
-      for (int c = lane; c < C; c += 64) dst[c] = xr[c] * rstd * norm_w[c];
+      const float rstd = row_rstd(xr);
+      for (int c = lane; c < cs; c += 64) dst[c] = xr[c0 + c] * rstd * norm_w[c0 + c];
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < tr * C; idx += blockDim.x) {
-    const int tt = idx / C, c = idx - tt * C;
-    float s = dw_b[c];
+  for (int idx = tid; idx < tr * cs; idx += blockDim.x) {
+    const int tt = idx / cs, c = idx - tt * cs;
+    const int cg = c0 + c;
+    float s = dw_b[cg];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) s = fmaf(dw_w[c * 7 + k], sm[(int64_t)(tt + k) * C + c], s);
-    const int64_t o = (int64_t)(t0 + tt) * C + c;
-    out[o] = x[o] + gamma[c] * s;
+    for (int k = 0; k < 7; ++k) s = fmaf(dw_w[cg * 7 + k], sm[(int64_t)(tt + k) * CS + c], s);
+    const int64_t o = (int64_t)(t0 + tt) * C + cg;
+    out[o] = x[o] + gamma[cg] * s;
   }
   if (hist && blockIdx.x == 0) {
-    // new history = last 6 rows of [old history ; normalised x rows].  Block 0 is the only reader of hist (its halo,
-    // already copied into sm rows 0..5 before the barrier above), so it is also the only writer; rows outside its tile
-    // are re-normalised here.
+    // new history = last 6 rows of [old history ; normalised x rows], for this block's channel slice.  Row tile 0 is the
+    // only reader of hist (its halo, already in sm rows 0..5 before the barrier above), so it is also the only writer;
+    // rows outside its tile are re-normalised here.
     for (int j = wave; j < 6; j += 4) {
       const int src = T - 6 + j;             // row of x; negative -> old history row j+T
-      float* dst = hist + (int64_t)j * C;
+      float* dst = hist + (int64_t)j * C + c0;
       if (src < 0) {
-        for (int c = lane; c < C; c += 64) dst[c] = sm[(int64_t)(j + T) * C + c];
+        for (int c = lane; c < cs; c += 64) dst[c] = sm[(int64_t)(j + T) * CS + c];
       } else if (src < tr) {
-        for (int c = lane; c < C; c += 64) dst[c] = sm[(int64_t)(src + 6) * C + c];
+        for (int c = lane; c < cs; c += 64) dst[c] = sm[(int64_t)(src + 6) * CS + c];
       } else {
         const float* xr = x + (int64_t)src * C;
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
-        s = wave_sum(s);
-        const float rstd = rsqrtf(s / (float)C + eps);
-        for (int c = lane; c < C; c += 64) dst[c] = xr[c] * rstd * norm_w[c];
+        const float rstd = row_rstd(xr);
+        for (int c = lane; c < cs; c += 64) dst[c] = xr[c0 + c] * rstd * norm_w[c0 + c];
       }
     }
   }
@@ -726,16 +780,18 @@ extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const fl
   if (!x || !out || !norm_w || !dw_w || !dw_b || !gamma) return vv_set_error(VV_E_ARG, "vv_block_mixer: null pointer");
   if (x == out) return vv_set_error(VV_E_ARG, "vv_block_mixer: in-place not allowed (halo rows)");
   if (T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_block_mixer: bad shape");
-  int TR = 15360 / C - 6;                       // (TR + 6) * C * 4 <= 60 KB
-  if (TR > 64) TR = 64;
-  if (TR > T) TR = T;
-  if (TR < 1) TR = 1;
-  const size_t lds = (size_t)(TR + 6) * C * sizeof(float);
+  // channel slice: whole rows when C is narrow; otherwise split channels until ~64 blocks exist (rows are few when C is wide)
+  int CS = C;
+  auto tiles_for = [&](int cs) { int tr = 15360 / cs - 6; if (tr > 64) tr = 64; if (tr > T) tr = T; if (tr < 1) tr = 1; return tr; };
+  while (CS > 64 && (CS > 1024 || (long)((T + tiles_for(CS) - 1) / tiles_for(CS)) * ((C + CS - 1) / CS) < 64)) CS = (CS + 1) / 2;
+  const int TR = tiles_for(CS);
+  const size_t lds = (size_t)(TR + 6) * CS * sizeof(float);
   if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: C=%d too wide", C);
-  if (hist && TR < 6 && T > TR)   // blocks 1..5 would read hist while block 0 rewrites it
+  if (hist && TR < 6 && T > TR)   // row tiles 1..5 would read hist while tile 0 rewrites it
     return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: streaming with C=%d needs T<=%d rows per call (got %d)", C, TR, T);
-  hipLaunchKernelGGL(block_mixer_kernel, dim3((T + TR - 1) / TR), dim3(256), lds, (hipStream_t)stream, x, out, T, C, norm_w, eps,
-                     dw_w, dw_b, gamma, hist, TR);
+  dim3 grid((T + TR - 1) / TR, (C + CS - 1) / CS);
+  hipLaunchKernelGGL(block_mixer_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, out, T, C, norm_w, eps,
+                     dw_w, dw_b, gamma, hist, TR, CS);
   VV_CHECK_LAUNCH("vv_block_mixer");
   return 0;
 }
