@@ -35,6 +35,7 @@ enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
 
 const char* vv_last_error(void);
 int vv_abi_version(void);
+int vv_init(void); /* one-time per-process kernel attribute setup; call before any graph capture */
 
 /* ------------------------------------------------------------------------------------------------------------
  * vv_linear — out[m, n] = epilogue( sum_k W[n, k] * prologue(x)[m, k] )

@@ -91,7 +91,9 @@ def test_linear_shapes(lib, m, n, k, wdtype):
     L.check(l.vv_linear(C.byref(a), None), "vv_linear")
     torch.cuda.synchronize()
     ref = _ref_linear(x, w.float(), None, bias, 0, None, 0, None, None, 0, None, res)
-    assert rel_rms(out.cpu().numpy(), ref.numpy()) < 2e-6
+    # bf16 weights with more than 8 rows run on the matrix cores with activations rounded to bf16 at staging
+    tol = 4e-3 if (wdtype == torch.bfloat16 and m > 8) else 2e-6
+    assert rel_rms(out.cpu().numpy(), ref.numpy()) < tol
 
 
 @pytest.mark.parametrize("m", [2, 24])

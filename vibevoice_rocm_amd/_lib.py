@@ -90,6 +90,7 @@ _STRUCTS = dict(vv_prof_entry=ProfEntry, vv_lin_args=LinArgs, vv_kv=KV, vv_llm_l
 PROTOTYPES = {
     "vv_last_error": (C.c_char_p, []),
     "vv_abi_version": (C.c_int, []),
+    "vv_init": (C.c_int, []),
     "vv_linear": (C.c_int, [C.POINTER(LinArgs), vp]),
     "vv_rope_store": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, vp]),
     "vv_attn": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, i64, vp]),
@@ -148,8 +149,19 @@ def load():
         n = lib.vv_sizeof(cname.encode())
         if n != C.sizeof(cls):
             raise VVError(f"ABI mismatch for {cname}: C side {n} bytes, ctypes mirror {C.sizeof(cls)} bytes")
+    rc = lib.vv_init() if _gpu_present() else 0
+    if rc != 0:
+        raise VVError(f"vv_init failed ({rc}): {lib.vv_last_error().decode()}")
     _lib = lib
     return lib
+
+
+def _gpu_present() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
 
 
 def check(rc: int, what: str = ""):

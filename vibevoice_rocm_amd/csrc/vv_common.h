@@ -21,6 +21,8 @@ int vv_set_error(int code, const char* fmt, ...);
   } while (0)
 
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_stream.hip: 1 = launched, 0 = not covered
+int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
+int vv_mfma_gemm_init();
 int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s);
 
 #endif

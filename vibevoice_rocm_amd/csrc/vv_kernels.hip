@@ -30,6 +30,7 @@ int vv_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* vv_last_error(void) { return g_err; }
 extern "C" int vv_abi_version(void) { return 1; }
+extern "C" int vv_init(void) { return vv_mfma_gemm_init(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
@@ -473,6 +474,11 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL((gemv_generic_kernel<WT>), dim3(blocks), dim3(GEMV_THREADS), 0, s, a);
     return 0;
+  }
+  {
+    const int rc = vv_launch_mfma_gemm(a, s);     // bf16 weights: matrix-core path
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
   }
   const bool vec = (a.k % 4 == 0) && (a.ldx % 4 == 0) && ((uintptr_t)a.x % 16 == 0) && w_al16;
   const long big_tiles = (long)((a.n + 63) / 64) * ((a.m + 63) / 64);

@@ -1,0 +1,215 @@
+// vv_mfma_gemm.hip — M > 8 rows against bf16 weights on the gfx950 matrix cores (mfma_f32_32x32x16_bf16).
+//
+// Used where the path really is GEMM shaped: the conv-tokenizer stages with T >= 8 time steps per frame (FFN linears,
+// dense / transposed convs read in place as overlapping-row GEMMs), the hoisted adaLN modulation of all diffusion steps,
+// the voice-prompt encoder and the LLM prompt prefill.  These problems are small and latency bound, not flop bound:
+// the point of MFMA here is that one wave finishes a 32(out-channel) x 32(row) tile per 16 k-elements with a single
+// 16-byte weight load per lane, so a tile's whole K loop is a short stream of independent loads instead of
+// hundreds of LDS-staged barrier rounds.
+//   D[n, m] = sum_k W[n, k] * Xhat[m, k]      A operand = weight fragment, straight from global (rows are K-contiguous)
+//                                             B operand = activation fragment from an LDS image of the 32-row tile
+//   Xhat = bf16( prologue(x) )  staged per workgroup (fp32 -> RMSNorm / modulate / SiLU -> bf16), row pitch padded by
+//   16 B so the 32 rows of a ds_read_b128 land on distinct bank groups.
+// Two wave layouts: 4 waves = 4 adjacent 32-channel blocks (wide N), or 4 waves = 4 K slices of one block combined
+// through LDS in a fixed order (narrow N, long K): deterministic, no atomics.
+// Activations are rounded to bf16 once at staging (the reference's bf16 run keeps them in bf16 throughout); the
+// fp32-weight parity mode never comes here.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "vv_hip.h"
+#include "vv_common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KCH = 1024;                 // K elements of the activation tile resident in LDS at a time
+constexpr int PITCH = KCH + 8;            // bf16 elements per LDS row (16-byte pad)
+
+__device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+  const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+  return (unsigned int)(*reinterpret_cast<const bf16_t*>(&x)) | ((unsigned int)(*reinterpret_cast<const bf16_t*>(&y)) << 16);
+}
+__device__ __forceinline__ void epi1(const vv_lin_args& a, int m, int n, float v, float v2) {
+  if (a.bias) v += a.bias[n];
+  if (a.act == VV_ACT_GELU) v = gelu1(v);
+  else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
+  if (a.gate) v *= a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n];
+  if (a.res) v += a.res[(int64_t)m * a.ldres + n];
+  a.out[(int64_t)m * a.ldo + n] = v;
+}
+
+template <bool DUAL, bool KSPLIT>
+__global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                    // [32][PITCH]
+  float* rs = reinterpret_cast<float*>(smem + 32 * PITCH * 2);      // [32] row rstd
+  float* red = reinterpret_cast<float*>(smem);                      // K-split combine scratch (aliases xs after the loop)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.m, N = a.n, K = a.k;
+  const int m0 = blockIdx.y * 32;
+  const int nblk = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
+  const int n0 = nblk * 32;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
+  const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
+
+  // ---- per-row RMS statistic of the tile (whole K) -------------------------------------------------------------
+  if (a.pro == VV_PRO_RMSNORM) {
+    const int r = tid >> 3, q = tid & 7;
+    float s = 0.f;
+    if (m0 + r < M) {
+      const float* xr = a.x + (int64_t)(m0 + r) * a.ldx;
+      for (int k = q * 4; k < K; k += 32) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + k);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (q == 0) rs[r] = rsqrtf(s / (float)K + a.eps);
+  }
+
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+  const int wr = min(n0 + (lane & 31), N - 1);                      // weight row of this lane (clamped; masked at the store)
+  const int hk = (lane >> 5) * 8;                                    // k offset of this lane inside a 16-wide step
+  const bf16_t* wrow = W + (int64_t)wr * K + hk;
+  const bf16_t* wrow2 = DUAL ? (W2 + (int64_t)wr * K + hk) : nullptr;
+  const bf16_t* xfrag = xs + (lane & 31) * PITCH + hk;
+  const bool active = n0 < N;
+
+  for (int kc0 = 0; kc0 < K; kc0 += KCH) {
+    const int kc = min(KCH, K - kc0);
+    __syncthreads();                                                 // rs visible / previous chunk fully consumed
+    // ---- stage Xhat[32, kc] ------------------------------------------------------------------------------------
+    {
+      const int r = tid >> 3, q = tid & 7;
+      const bool rv = m0 + r < M;
+      const float* xr = a.x + (int64_t)(rv ? m0 + r : 0) * a.ldx + kc0;
+      const float rstd = (a.pro == VV_PRO_RMSNORM) ? rs[r] : 1.f;
+      for (int k = q * 4; k < kc; k += 32) {
+        float4 v = rv ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.pro == VV_PRO_RMSNORM) {
+          v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+          if (a.norm_w) { const float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + kc0 + k); v.x *= w4.x; v.y *= w4.y; v.z *= w4.z; v.w *= w4.w; }
+          if (a.mod_scale && rv) {
+            const int64_t mo = (int64_t)(m0 + r) * a.ld_mod + kc0 + k;
+            v.x = v.x * (1.f + a.mod_scale[mo]) + a.mod_shift[mo];
+            v.y = v.y * (1.f + a.mod_scale[mo + 1]) + a.mod_shift[mo + 1];
+            v.z = v.z * (1.f + a.mod_scale[mo + 2]) + a.mod_shift[mo + 2];
+            v.w = v.w * (1.f + a.mod_scale[mo + 3]) + a.mod_shift[mo + 3];
+          }
+        } else if (a.pro == VV_PRO_SILU) {
+          v.x = silu1(v.x); v.y = silu1(v.y); v.z = silu1(v.z); v.w = silu1(v.w);
+        }
+        uint2 p;
+        p.x = pack2(v.x, v.y);
+        p.y = pack2(v.z, v.w);
+        *reinterpret_cast<uint2*>(xs + r * PITCH + k) = p;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const int nsteps = kc >> 4;
+      int s_begin = 0, s_end = nsteps;
+      if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
+#pragma unroll 4
+      for (int s = s_begin; s < s_end; ++s) {
+        const u32x4 wa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + kc0 + s * 16));
+        const u32x4 xb = *reinterpret_cast<const u32x4*>(xfrag + s * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+        if (DUAL) {
+          const u32x4 wb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + kc0 + s * 16));
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, xb), acc2, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: D[n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][m = lane&31] ----------------------------------------------
+  if (!KSPLIT) {
+    if (!active) return;
+    const int m = m0 + (lane & 31);
+    if (m >= M) return;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      if (n < N) epi1(a, m, n, acc[reg], DUAL ? acc2[reg] : 0.f);
+    }
+  } else {
+    __syncthreads();                                                 // xs no longer needed: reuse as red[4][2][16][64]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      red[((wave * 2 + 0) * 16 + reg) * 64 + lane] = acc[reg];
+      if (DUAL) red[((wave * 2 + 1) * 16 + reg) * 64 + lane] = acc2[reg];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      const int reg = e >> 6, ln = e & 63;
+      const int m = m0 + (ln & 31);
+      const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+      if (m < M && n < N) {
+        float v = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {                             // fixed order: deterministic
+          v += red[((w4 * 2 + 0) * 16 + reg) * 64 + ln];
+          if (DUAL) v2 += red[((w4 * 2 + 1) * 16 + reg) * 64 + ln];
+        }
+        epi1(a, m, n, v, v2);
+      }
+    }
+  }
+}
+
+constexpr size_t LDS_BYTES = 32 * PITCH * 2 + 32 * 4 + 64;
+
+template <bool DUAL, bool KSPLIT>
+int launch(const vv_lin_args& a, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<DUAL, KSPLIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma_linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  const int nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
+  dim3 grid(KSPLIT ? nblocks : (nblocks + 3) / 4, rtiles);
+  if (grid.y > 65535u) return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: m=%d rows exceed one launch (split the call)", a.m);
+  hipLaunchKernelGGL((mfma_linear_kernel<DUAL, KSPLIT>), grid, dim3(256), LDS_BYTES, s, a);
+  return 0;
+}
+
+}  // namespace
+
+// 1 = launched, 0 = shape/alignment not covered (caller falls back to the fp32 VALU GEMM), < 0 = error
+int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
+  if (a.wdt != VV_BF16 || a.m <= 8 || a.k % 16 || a.ldx % 4) return 0;
+  if ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16) || (uintptr_t)a.x % 16) return 0;
+  if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
+  if ((a.k * 2) % 16) return 0;
+  const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
+  const bool ksplit = (nblocks * rtiles < 256) && a.k >= 256;       // too few waves otherwise: split K inside the workgroup
+  int rc;
+  if (a.w2) rc = ksplit ? launch<true, true>(a, s) : launch<true, false>(a, s);
+  else rc = ksplit ? launch<false, true>(a, s) : launch<false, false>(a, s);
+  return rc ? rc : 1;
+}
+
+// graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
+int vv_mfma_gemm_init() {
+  hipError_t e;
+#define VV_ATTR(D, S)                                                                                                   \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)LDS_BYTES);                                                                                \
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma init: %s", hipGetErrorString(e));
+  VV_ATTR(false, false) VV_ATTR(false, true) VV_ATTR(true, false) VV_ATTR(true, true)
+#undef VV_ATTR
+  return 0;
+}
