@@ -35,6 +35,7 @@ enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
 
 const char* vv_last_error(void);
 int vv_abi_version(void);
+int vv_tune(const char* key, int value); /* developer tuning hook (grid-size overrides for micro-benchmarks) */
 int vv_init(void); /* one-time per-process kernel attribute setup; call before any graph capture */
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -99,6 +100,10 @@ int vv_rope_store(float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv,
                   const int* lens, const int* cache_rows, vv_stream_t stream);
 int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const int* lens,
             const int* cache_rows, float* out, int64_t ldo, vv_stream_t stream);
+/* vv_attn_decode: vv_rope_store + vv_attn fused for the per-frame step (row r appends to cache row r): qkv is the raw
+ * projection (pre-RoPE); q and the new k are rotated in registers, k/v appended at slot lens[r], attention over 0..lens[r]. */
+int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+                   const int* lens, float* out, int64_t ldo, vv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Block1D first half on channels-last data (modular_vibevoice_tokenizer.py:924-932 with the streaming

@@ -91,9 +91,11 @@ PROTOTYPES = {
     "vv_last_error": (C.c_char_p, []),
     "vv_abi_version": (C.c_int, []),
     "vv_init": (C.c_int, []),
+    "vv_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "vv_linear": (C.c_int, [C.POINTER(LinArgs), vp]),
     "vv_rope_store": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, vp]),
     "vv_attn": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, i64, vp]),
+    "vv_attn_decode": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, i64, vp]),
     "vv_block_mixer": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp]),
     "vv_conv_ctx": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "vv_affine": (C.c_int, [vp, C.c_float, C.c_float, vp, i64, vp]),

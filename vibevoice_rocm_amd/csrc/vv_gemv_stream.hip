@@ -43,6 +43,7 @@ __device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v,
 }
 
 constexpr int RW = 2;   // weight rows per wave step
+int g_blocks_override = 0;   // tuning hook (vv_tune)
 
 template <int M, bool DUAL, int KSPLIT, int KU>
 __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
@@ -220,6 +221,7 @@ void launch_one(const vv_lin_args& a, hipStream_t s) {
   const int resident = DUAL ? 512 : 1024;
   const int rounds = (work + resident - 1) / resident;
   int blocks = (work + rounds - 1) / rounds;
+  if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
   hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU>), dim3(blocks), dim3(256), 0, s, a, n_groups);
 }
 
@@ -248,6 +250,8 @@ bool launch_ku(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
 }
 
 }  // namespace
+
+void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
 
 // returns 1 when the call was launched here, 0 when the shape/alignment is not covered (caller falls back)
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {

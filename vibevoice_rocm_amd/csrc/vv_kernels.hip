@@ -31,6 +31,11 @@ int vv_set_error(int code, const char* fmt, ...) {
 extern "C" const char* vv_last_error(void) { return g_err; }
 extern "C" int vv_abi_version(void) { return 1; }
 extern "C" int vv_init(void) { return vv_mfma_gemm_init(); }
+void vv_gemv_stream_set_blocks(int b);
+extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
+  if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
+  return vv_set_error(VV_E_ARG, "vv_tune: unknown key");
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
@@ -720,6 +725,141 @@ extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Decode attention with RoPE and the KV append fused in (rows own distinct cache rows: the per-frame {positive, negative}
+// step).  q and the new k are rotated in registers; keys 0..pos-1 come from the cache, the new token's k/v straight from
+// the projection buffer (so no block depends on another block's cache write); the first q head of each kv group appends
+// k, v at slot pos.  512 threads, 4 keys in flight per lane group: S ~ 500 is four round trips instead of thirty.
+// ---------------------------------------------------------------------------------------------------------------
+#define ATT_UNR 4
+template <typename KT, int EPL>
+__global__ __launch_bounds__(512) void attn_fused_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
+                                                         const float* inv_freq, const int* lens, float* out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int r = blockIdx.y, h = blockIdx.x;
+  const int d = kv.head_dim, half = d >> 1;
+  const int G = d / EPL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NW = 8;
+  const int gl = lane % G, gi = lane / G;
+  const int KPW = 64 / G;
+  const int pos = lens[r];
+  const int gsz = heads / kv.kv_heads;
+  const int kvh = h / gsz;
+  const int64_t base = ((((int64_t)layer * kv.rows + r) * kv.kv_heads + kvh) * kv.s_max) * d;
+  KT* kcw = reinterpret_cast<KT*>(kv.k) + base;
+  KT* vcw = reinterpret_cast<KT*>(kv.v) + base;
+  const KT* kc = kcw;
+  const KT* vc = vcw;
+  const float scale = rsqrtf((float)d);
+  const float* row = qkv + (int64_t)r * ld;
+  // rotate this lane's slice of q and of the new k (half rotation: pair (i, i + d/2))
+  const int e0 = gl * EPL;
+  const bool lo = e0 < half;
+  const int pe0 = lo ? e0 + half : e0 - half;
+  float q[EPL], kn[EPL], vn[EPL];
+  {
+    const float* qp = row + h * d;
+    const float* kp = row + (heads + kvh) * d;
+    const float* vp = row + (heads + kv.kv_heads + kvh) * d;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      const int fi = (lo ? e0 : pe0) + j;                 // frequency index in [0, d/2)
+      const float ang = (float)pos * inv_freq[fi];
+      const float c = cosf(ang), sn = sinf(ang);
+      const float qa = qp[e0 + j], qb = qp[pe0 + j];
+      const float ka = kp[e0 + j], kb = kp[pe0 + j];
+      q[j] = (lo ? qa * c - qb * sn : qa * c + qb * sn) * scale;
+      kn[j] = lo ? ka * c - kb * sn : ka * c + kb * sn;
+      vn[j] = vp[e0 + j];
+    }
+  }
+  if (h % gsz == 0 && wave == 0 && gi == 0) {             // one writer per (row, kv head)
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      kv_store<KT>(kcw + (int64_t)pos * d + e0 + j, kn[j]);
+      kv_store<KT>(vcw + (int64_t)pos * d + e0 + j, vn[j]);
+    }
+  }
+  float mmax = -INFINITY, lsum = 0.f, acc[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+  auto update = [&](float dot, const float (&vx)[EPL]) {
+    const float mn = fmaxf(mmax, dot);
+    const float corr = expf(mmax - mn);
+    const float p = expf(dot - mn);
+    lsum = lsum * corr + p;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vx[j], acc[j] * corr);
+    mmax = mn;
+  };
+  const int stride = NW * KPW * ATT_UNR;
+  for (int s0 = (wave * ATT_UNR) * KPW; s0 < pos; s0 += stride) {
+    float kx[ATT_UNR][EPL], vx[ATT_UNR][EPL];
+    bool valid[ATT_UNR];
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      const int s = s0 + u * KPW + gi;
+      valid[u] = s < pos;
+      const int sc = valid[u] ? s : 0;
+      load_epl<KT, EPL>(kc + (int64_t)sc * d + e0, kx[u]);
+      load_epl<KT, EPL>(vc + (int64_t)sc * d + e0, vx[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) dot = fmaf(q[j], kx[u][j], dot);
+      for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+      if (valid[u]) update(dot, vx[u]);
+    }
+  }
+  {   // the new token itself (every block needs it; the cache copy may not be written yet by its owner block)
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) dot = fmaf(q[j], kn[j], dot);
+    for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (wave == 0 && gi == 0) update(dot, vn);
+  }
+  const int ng = NW * KPW;
+  const int g = wave * KPW + gi;
+  float* rec = sm + (int64_t)g * (d + 2);
+  if (gl == 0) { rec[0] = mmax; rec[1] = lsum; }
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) rec[2 + e0 + j] = acc[j];
+  __syncthreads();
+  for (int i = tid; i < d; i += blockDim.x) {
+    float M = -INFINITY;
+    for (int gg = 0; gg < ng; ++gg) M = fmaxf(M, sm[(int64_t)gg * (d + 2)]);
+    float num = 0.f, den = 0.f;
+    for (int gg = 0; gg < ng; ++gg) {
+      const float* rr = sm + (int64_t)gg * (d + 2);
+      const float wgt = (rr[0] == -INFINITY) ? 0.f : expf(rr[0] - M);
+      den = fmaf(rr[1], wgt, den);
+      num = fmaf(rr[2 + i], wgt, num);
+    }
+    out[(int64_t)r * ldo + h * d + i] = num / den;
+  }
+}
+
+extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+                              const int* lens, float* out, int64_t ldo, vv_stream_t stream) {
+  if (!qkv || !kv || !lens || !out || !inv_freq) return vv_set_error(VV_E_ARG, "vv_attn_decode: null pointer");
+  if (layer < 0 || layer >= kv->layers || R <= 0 || R > kv->rows || heads % kv->kv_heads) return vv_set_error(VV_E_ARG, "vv_attn_decode: bad layer/R/heads");
+  const int d = kv->head_dim;
+  const int epl = kv->kvdt == VV_F32 ? 4 : 8;
+  if (d % 2 || d % epl || 64 % (d / epl) || d / epl > 64 || (d / 2) % epl) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn_decode: head_dim %d unsupported", d);
+  const int G = d / epl, ng = 8 * (64 / G);
+  const size_t lds = (size_t)ng * (d + 2) * sizeof(float);
+  if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn_decode: LDS %zu too large", lds);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(heads, R);
+  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_fused_kernel<float, 4>), grid, dim3(512), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  else hipLaunchKernelGGL((attn_fused_kernel<bf16_t, 8>), grid, dim3(512), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  VV_CHECK_LAUNCH("vv_attn_decode");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Block1D mixer: out = x + gamma * (dwconv7(RMSNorm_c(x)) + b), channels-last, streaming history of normalised rows
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C,
@@ -739,16 +879,31 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
     s = wave_sum(s);
     return rsqrtf(s / (float)C + eps);
   };
-  // rows t0-6 .. t0+tr-1 -> sm rows 0 .. tr+5
-  for (int rr = wave; rr < tr + 6; rr += 4) {
-    const int t = t0 - 6 + rr;
-    float* dst = sm + (int64_t)rr * CS;
-    if (t < 0) {
-      for (int c = lane; c < cs; c += 64) dst[c] = hist ? hist[(int64_t)(6 + t) * C + c0 + c] : 0.f;   // t in [-6,-1] -> hist row 6+t
-    } else {
-      const float* xr = x + (int64_t)t * C;
-      const float rstd = row_rstd(xr);
-      for (int c = lane; c < cs; c += 64) dst[c] = xr[c0 + c] * rstd * norm_w[c0 + c];
+  // rows t0-6 .. t0+tr-1 -> sm rows 0 .. tr+5; each wave keeps 4 rows' statistics in flight at once
+  for (int rb = wave * 4; rb < tr + 6; rb += 16) {
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 - 6 + rb + u;
+      xr[u] = (rb + u < tr + 6 && t >= 0) ? x + (int64_t)t * C : nullptr;
+    }
+    for (int c = lane; c < C; c += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (xr[u]) { const float v = xr[u][c]; ss[u] = fmaf(v, v, ss[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = rb + u;
+      if (rr >= tr + 6) break;
+      const int t = t0 - 6 + rr;
+      float* dst = sm + (int64_t)rr * CS;
+      if (t < 0) {
+        for (int c = lane; c < cs; c += 64) dst[c] = hist ? hist[(int64_t)(6 + t) * C + c0 + c] : 0.f;   // t in [-6,-1] -> hist row 6+t
+      } else {
+        const float rstd = rsqrtf(wave_sum(ss[u]) / (float)C + eps);
+        for (int c = lane; c < cs; c += 64) dst[c] = xr[u][c0 + c] * rstd * norm_w[c0 + c];
+      }
     }
   }
   __syncthreads();

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       const int nsteps = kc >> 4;
       int s_begin = 0, s_end = nsteps;
       if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
-#pragma unroll 4
+#pragma unroll 8
       for (int s = s_begin; s < s_end; ++s) {
         const u32x4 wa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + kc0 + s * 16));
         const u32x4 xb = *reinterpret_cast<const u32x4*>(xfrag + s * 16);
@@ -195,7 +195,9 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if ((a.k * 2) % 16) return 0;
   const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
-  const bool ksplit = (nblocks * rtiles < 256) && a.k >= 256;       // too few waves otherwise: split K inside the workgroup
+  // a wave's K loop is a serial chain of 16-element steps: split K over the workgroup's 4 waves whenever K is long, or when
+  // there are too few 32x32 tiles to fill the chip anyway
+  const bool ksplit = a.k >= 512 || ((nblocks * rtiles < 256) && a.k >= 128);
   int rc;
   if (a.w2) rc = ksplit ? launch<true, true>(a, s) : launch<true, false>(a, s);
   else rc = ksplit ? launch<false, true>(a, s) : launch<false, false>(a, s);

@@ -58,8 +58,12 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     vv_lin_args a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
     a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
     VV_TRY(vv_linear(&a, stream));
-    VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, m->inv_freq, lens, cache_rows, stream));
-    VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
+    if (cache_rows == nullptr && R <= kv->rows) {
+      VV_TRY(vv_attn_decode(qkv, qkvd, R, m->heads, kv, l, m->inv_freq, lens, att, qd, stream));   // decode: RoPE + append fused
+    } else {
+      VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, m->inv_freq, lens, cache_rows, stream));
+      VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
+    }
     a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
     a.res = h; a.ldres = H;
     VV_TRY(vv_linear(&a, stream));
