@@ -96,13 +96,15 @@ typedef struct vv_kv {
   int kvdt, layers, rows, kv_heads, s_max, head_dim;
 } vv_kv;
 
-int vv_rope_store(float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+/* rope_table[R][head_dim/2][2] = {cos, sin}(lens[r] * inv_freq[i]): computed once per step, shared by all layers */
+int vv_rope_table(const int* lens, const float* inv_freq, int R, int head_dim, float* rope_table, vv_stream_t stream);
+int vv_rope_store(float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table,
                   const int* lens, const int* cache_rows, vv_stream_t stream);
 int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const int* lens,
             const int* cache_rows, float* out, int64_t ldo, vv_stream_t stream);
 /* vv_attn_decode: vv_rope_store + vv_attn fused for the per-frame step (row r appends to cache row r): qkv is the raw
  * projection (pre-RoPE); q and the new k are rotated in registers, k/v appended at slot lens[r], attention over 0..lens[r]. */
-int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table,
                    const int* lens, float* out, int64_t ldo, vv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "vv_init": (C.c_int, []),
     "vv_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "vv_linear": (C.c_int, [C.POINTER(LinArgs), vp]),
+    "vv_rope_table": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "vv_rope_store": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, vp]),
     "vv_attn": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, i64, vp]),
     "vv_attn_decode": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, i64, vp]),

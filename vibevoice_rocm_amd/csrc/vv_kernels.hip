@@ -582,9 +582,26 @@ template <> __device__ __forceinline__ void kv_store<bf16_t>(bf16_t* p, float v)
   *p = *reinterpret_cast<const bf16_t*>(&b);
 }
 
+// cos/sin of (position * inv_freq) for every row of a step: computed ONCE per LLM step (accurate cosf/sinf with large
+// arguments cost hundreds of instructions) and shared by all layers' RoPE.  table[r][i] = {cos, sin}, i < head_dim/2.
+__global__ void rope_table_kernel(const int* lens, const float* inv_freq, int half, float2* table) {
+  const int r = blockIdx.x;
+  const float pos = (float)lens[r];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float ang = pos * inv_freq[i];
+    table[(int64_t)r * half + i] = make_float2(cosf(ang), sinf(ang));
+  }
+}
+extern "C" int vv_rope_table(const int* lens, const float* inv_freq, int R, int head_dim, float* table, vv_stream_t stream) {
+  if (!lens || !inv_freq || !table || R <= 0 || head_dim <= 0 || head_dim % 2) return vv_set_error(VV_E_ARG, "vv_rope_table: bad args");
+  hipLaunchKernelGGL(rope_table_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, lens, inv_freq, head_dim / 2, reinterpret_cast<float2*>(table));
+  VV_CHECK_LAUNCH("vv_rope_table");
+  return 0;
+}
+
 template <typename KT>
 __global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
-                                                         const float* inv_freq, const int* lens, const int* cache_rows) {
+                                                         const float2* rope, const int* lens, const int* cache_rows) {
   const int r = blockIdx.x;
   const int d = kv.head_dim, half = d >> 1;
   const int pos = lens[r];
@@ -599,8 +616,8 @@ __global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int64_t ld,
     const int j = isq ? idx : idx - nq;
     const int h = j / half, i = j - h * half;
     float* p = row + (isq ? 0 : heads * d) + h * d;
-    const float ang = (float)pos * inv_freq[i];
-    const float c = cosf(ang), s = sinf(ang);
+    const float2 cs = rope[(int64_t)r * half + i];
+    const float c = cs.x, s = cs.y;
     const float x1 = p[i], x2 = p[i + half];
     const float y1 = x1 * c - x2 * s;         // q*cos + rotate_half(q)*sin, first half: -x2
     const float y2 = x2 * c + x1 * s;         // second half: +x1
@@ -618,8 +635,9 @@ __global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int64_t ld,
   }
 }
 
-extern "C" int vv_rope_store(float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+extern "C" int vv_rope_store(float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table,
                              const int* lens, const int* cache_rows, vv_stream_t stream) {
+  const float2* inv_freq = reinterpret_cast<const float2*>(rope_table);
   if (!qkv || !kv || !inv_freq || !lens) return vv_set_error(VV_E_ARG, "vv_rope_store: null pointer");
   if (layer < 0 || layer >= kv->layers || R <= 0) return vv_set_error(VV_E_ARG, "vv_rope_store: bad layer/R");
   if (kv->head_dim % 2) return vv_set_error(VV_E_ARG, "vv_rope_store: odd head_dim");
@@ -732,14 +750,14 @@ extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const
 // ---------------------------------------------------------------------------------------------------------------
 #define ATT_UNR 4
 template <typename KT, int EPL>
-__global__ __launch_bounds__(512) void attn_fused_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
-                                                         const float* inv_freq, const int* lens, float* out, int64_t ldo) {
+__global__ __launch_bounds__(1024) void attn_fused_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
+                                                         const float2* rope, const int* lens, float* out, int64_t ldo) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int r = blockIdx.y, h = blockIdx.x;
   const int d = kv.head_dim, half = d >> 1;
   const int G = d / EPL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NW = 8;
+  const int NW = 16;
   const int gl = lane % G, gi = lane / G;
   const int KPW = 64 / G;
   const int pos = lens[r];
@@ -764,8 +782,8 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* qkv, int64
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
       const int fi = (lo ? e0 : pe0) + j;                 // frequency index in [0, d/2)
-      const float ang = (float)pos * inv_freq[fi];
-      const float c = cosf(ang), sn = sinf(ang);
+      const float2 cs = rope[(int64_t)r * half + fi];
+      const float c = cs.x, sn = cs.y;
       const float qa = qp[e0 + j], qb = qp[pe0 + j];
       const float ka = kp[e0 + j], kb = kp[pe0 + j];
       q[j] = (lo ? qa * c - qb * sn : qa * c + qb * sn) * scale;
@@ -820,18 +838,29 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* qkv, int64
     for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
     if (wave == 0 && gi == 0) update(dot, vn);
   }
-  const int ng = NW * KPW;
-  const int g = wave * KPW + gi;
-  float* rec = sm + (int64_t)g * (d + 2);
-  if (gl == 0) { rec[0] = mmax; rec[1] = lsum; }
+  // merge the lane groups of this wave with shuffles (each step pairs groups `o` lanes apart), then the waves through LDS
+  for (int o = G; o < 64; o <<= 1) {
+    const float m2 = __shfl_xor(mmax, o), l2 = __shfl_xor(lsum, o);
+    const float mn = fmaxf(mmax, m2);
+    const float c1 = (mmax == -INFINITY) ? 0.f : expf(mmax - mn);
+    const float c2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+    lsum = lsum * c1 + l2 * c2;
 #pragma unroll
-  for (int j = 0; j < EPL; ++j) rec[2 + e0 + j] = acc[j];
+    for (int j = 0; j < EPL; ++j) { const float a2 = __shfl_xor(acc[j], o); acc[j] = acc[j] * c1 + a2 * c2; }
+    mmax = mn;
+  }
+  float* rec = sm + (int64_t)wave * (d + 2);
+  if (gi == 0) {
+    if (gl == 0) { rec[0] = mmax; rec[1] = lsum; }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) rec[2 + e0 + j] = acc[j];
+  }
   __syncthreads();
   for (int i = tid; i < d; i += blockDim.x) {
     float M = -INFINITY;
-    for (int gg = 0; gg < ng; ++gg) M = fmaxf(M, sm[(int64_t)gg * (d + 2)]);
+    for (int gg = 0; gg < NW; ++gg) M = fmaxf(M, sm[(int64_t)gg * (d + 2)]);
     float num = 0.f, den = 0.f;
-    for (int gg = 0; gg < ng; ++gg) {
+    for (int gg = 0; gg < NW; ++gg) {
       const float* rr = sm + (int64_t)gg * (d + 2);
       const float wgt = (rr[0] == -INFINITY) ? 0.f : expf(rr[0] - M);
       den = fmaf(rr[1], wgt, den);
@@ -841,20 +870,20 @@ __global__ __launch_bounds__(512) void attn_fused_kernel(const float* qkv, int64
   }
 }
 
-extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* inv_freq,
+extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table,
                               const int* lens, float* out, int64_t ldo, vv_stream_t stream) {
+  const float2* inv_freq = reinterpret_cast<const float2*>(rope_table);
   if (!qkv || !kv || !lens || !out || !inv_freq) return vv_set_error(VV_E_ARG, "vv_attn_decode: null pointer");
   if (layer < 0 || layer >= kv->layers || R <= 0 || R > kv->rows || heads % kv->kv_heads) return vv_set_error(VV_E_ARG, "vv_attn_decode: bad layer/R/heads");
   const int d = kv->head_dim;
   const int epl = kv->kvdt == VV_F32 ? 4 : 8;
   if (d % 2 || d % epl || 64 % (d / epl) || d / epl > 64 || (d / 2) % epl) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn_decode: head_dim %d unsupported", d);
-  const int G = d / epl, ng = 8 * (64 / G);
-  const size_t lds = (size_t)ng * (d + 2) * sizeof(float);
+  const size_t lds = (size_t)16 * (d + 2) * sizeof(float);
   if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn_decode: LDS %zu too large", lds);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(heads, R);
-  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_fused_kernel<float, 4>), grid, dim3(512), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
-  else hipLaunchKernelGGL((attn_fused_kernel<bf16_t, 8>), grid, dim3(512), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_fused_kernel<float, 4>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  else hipLaunchKernelGGL((attn_fused_kernel<bf16_t, 8>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
   VV_CHECK_LAUNCH("vv_attn_decode");
   return 0;
 }

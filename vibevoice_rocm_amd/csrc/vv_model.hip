@@ -36,7 +36,8 @@ inline vv_lin_args lin_base(const float* x, int64_t ldx, int m, const void* w, i
 extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   if (!m || R <= 0) return 0;
   const size_t qkv = (size_t)(m->heads + 2 * m->kv_heads) * m->head_dim;
-  return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter);
+  return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter) +
+         al((size_t)R * m->head_dim);
 }
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
@@ -52,16 +53,18 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   float* qkv = c.take((size_t)R * qkvd);
   float* att = c.take((size_t)R * qd);
   float* act = c.take((size_t)R * m->inter);
+  float* rope = c.take((size_t)R * d);
   VV_TRY(vv_copy_rows(x, ldx, h, H, R, H, stream));
+  VV_TRY(vv_rope_table(lens, m->inv_freq, R, d, rope, stream));
   for (int l = 0; l < m->layers; ++l) {
     const vv_llm_layer& L = m->layer[l];
     vv_lin_args a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
     a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
     VV_TRY(vv_linear(&a, stream));
     if (cache_rows == nullptr && R <= kv->rows) {
-      VV_TRY(vv_attn_decode(qkv, qkvd, R, m->heads, kv, l, m->inv_freq, lens, att, qd, stream));   // decode: RoPE + append fused
+      VV_TRY(vv_attn_decode(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, stream));   // decode: RoPE + append fused
     } else {
-      VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, m->inv_freq, lens, cache_rows, stream));
+      VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, rope, lens, cache_rows, stream));
       VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
     }
     a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
