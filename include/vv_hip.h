@@ -32,6 +32,10 @@ enum { VV_F32 = 0, VV_BF16 = 1 };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_HIP = -2, VV_E_UNSUPPORTED = -3 };
 enum { VV_PRO_NONE = 0, VV_PRO_RMSNORM = 1, VV_PRO_SILU = 2 };
 enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
+/* vv_lin_args.flags: bf16 activation hand-off between two matrix-core GEMMs (x / out point at bf16 [m, ld] arrays, no
+ * prologue on a bf16 x), and a hint that the weights are re-read soon (keep them cacheable instead of streaming them
+ * non-temporally: the diffusion head's matrices are reused by every one of the N solver steps of a frame) */
+enum { VV_LIN_X_BF16 = 1, VV_LIN_OUT_BF16 = 2, VV_LIN_W_REUSED = 4 };
 
 const char* vv_last_error(void);
 int vv_abi_version(void);
@@ -75,6 +79,7 @@ typedef struct vv_lin_args {
   int64_t ldres;
   float* out;
   int64_t ldo;
+  int flags;   /* VV_LIN_* */
 } vv_lin_args;
 
 int vv_linear(const vv_lin_args* a, vv_stream_t stream);

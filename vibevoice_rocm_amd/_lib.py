@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libvv_hip.so")
 VV_F32, VV_BF16 = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
+LIN_X_BF16, LIN_OUT_BF16, LIN_W_REUSED = 1, 2, 4
 VV_MAX_STAGES = 8
 
 vp = C.c_void_p
@@ -25,7 +26,7 @@ class LinArgs(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("m", C.c_int), ("pro", C.c_int), ("norm_w", vp), ("eps", C.c_float),
                 ("mod_shift", vp), ("mod_scale", vp), ("ld_mod", i64), ("w", vp), ("w2", vp), ("bias", vp),
                 ("n", C.c_int), ("k", C.c_int), ("wdt", C.c_int), ("act", C.c_int), ("gate", vp), ("gate_ld", i64),
-                ("res", vp), ("ldres", i64), ("out", vp), ("ldo", i64)]
+                ("res", vp), ("ldres", i64), ("out", vp), ("ldo", i64), ("flags", C.c_int)]
 
 
 class KV(C.Structure):

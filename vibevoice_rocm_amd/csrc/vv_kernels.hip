@@ -484,6 +484,7 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
     const int rc = vv_launch_mfma_gemm(a, s);     // bf16 weights: matrix-core path
     if (rc < 0) return rc;
     if (rc == 1) return 0;
+    if (a.flags & (VV_LIN_X_BF16 | VV_LIN_OUT_BF16)) return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: bf16 hand-off not covered for this shape/alignment");
   }
   const bool vec = (a.k % 4 == 0) && (a.ldx % 4 == 0) && ((uintptr_t)a.x % 16 == 0) && w_al16;
   const long big_tiles = (long)((a.n + 63) / 64) * ((a.m + 63) / 64);
@@ -554,6 +555,8 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   if (a->act != VV_ACT_SWIGLU && a->w2) return vv_set_error(VV_E_ARG, "vv_linear: w2 given without SWIGLU");
   if (a->mod_scale && (!a->mod_shift || a->pro != VV_PRO_RMSNORM)) return vv_set_error(VV_E_ARG, "vv_linear: modulate needs RMSNORM prologue and shift");
   if (a->m > 8 && a->ldx == 0) return vv_set_error(VV_E_ARG, "vv_linear: broadcast rows (ldx=0) only for m<=8");
+  if ((a->flags & (VV_LIN_X_BF16 | VV_LIN_OUT_BF16)) && (a->wdt != VV_BF16 || a->m <= 8 || a->k % 16))
+    return vv_set_error(VV_E_ARG, "vv_linear: bf16 activation hand-off needs bf16 weights, m > 8 and k %% 16 == 0");
   hipStream_t s = (hipStream_t)stream;
   int rc;
   ProfRec pr;
@@ -894,20 +897,25 @@ extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads
 __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C,
                                                           const float* norm_w, float eps, const float* dw_w, const float* dw_b,
                                                           const float* gamma, float* hist, int TR, int CS) {
-  // grid = (row tiles, channel slices).  A block owns rows [t0, t0+tr) x channels [c0, c0+cs); the per-row RMS statistic
-  // needs the whole row, so it is recomputed by every channel slice (only wide-C / short-T stages have > 1 slice).
+  // grid = (row tiles of TR rows, channel slices of CS <= 64 channels).  A lane owns one channel of the slice for the whole
+  // kernel (its norm weight, 7 taps, bias and layer scale sit in registers); the per-row RMS statistic needs the whole row,
+  // so every channel slice recomputes it (wide-C stages have few rows, long-T stages have one slice).
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [TR + 6][CS] normalised rows of this slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t0 = blockIdx.x * TR;
   const int tr = min(TR, T - t0);
   const int c0 = blockIdx.y * CS;
   const int cs = min(CS, C - c0);
-  auto row_rstd = [&](const float* xr) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
-    s = wave_sum(s);
-    return rsqrtf(s / (float)C + eps);
-  };
+  const int rpw = 64 / CS;                         // rows a wave covers per step in the output phase (CS = 64 or 32 or smaller pow2)
+  const int cl = lane % CS, rl = lane / CS;
+  const bool cv = cl < cs;
+  const int cg = c0 + (cv ? cl : 0);
+  // parameters of this lane's channel: issued first so their latency overlaps the statistics pass
+  const float nw = norm_w[cg], bb = dw_b[cg], gm = gamma[cg];
+  float tap[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) tap[k] = dw_w[cg * 7 + k];
+
   // rows t0-6 .. t0+tr-1 -> sm rows 0 .. tr+5; each wave keeps 4 rows' statistics in flight at once
   for (int rb = wave * 4; rb < tr + 6; rb += 16) {
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
@@ -936,14 +944,13 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < tr * cs; idx += blockDim.x) {
-    const int tt = idx / cs, c = idx - tt * cs;
-    const int cg = c0 + c;
-    float s = dw_b[cg];
+  for (int tt = wave * rpw + rl; tt < tr; tt += 4 * rpw) {
+    if (!cv) continue;
+    float s = bb;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) s = fmaf(dw_w[cg * 7 + k], sm[(int64_t)(tt + k) * CS + c], s);
+    for (int k = 0; k < 7; ++k) s = fmaf(tap[k], sm[(int64_t)(tt + k) * CS + cl], s);
     const int64_t o = (int64_t)(t0 + tt) * C + cg;
-    out[o] = x[o] + gamma[cg] * s;
+    out[o] = x[o] + gm * s;
   }
   if (hist && blockIdx.x == 0) {
     // new history = last 6 rows of [old history ; normalised x rows], for this block's channel slice.  Row tile 0 is the
@@ -957,12 +964,15 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
       } else if (src < tr) {
         for (int c = lane; c < cs; c += 64) dst[c] = sm[(int64_t)(src + 6) * CS + c];
       } else {
-        const float* xr = x + (int64_t)src * C;
-        const float rstd = row_rstd(xr);
-        for (int c = lane; c < cs; c += 64) dst[c] = xr[c0 + c] * rstd * norm_w[c0 + c];
+        const float* xs = x + (int64_t)src * C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = xs[c]; q = fmaf(v, v, q); }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        for (int c = lane; c < cs; c += 64) dst[c] = xs[c0 + c] * rstd * norm_w[c0 + c];
       }
     }
   }
+  (void)nw;
 }
 
 extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const float* norm_w, float eps, const float* dw_w,
@@ -970,16 +980,14 @@ extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const fl
   if (!x || !out || !norm_w || !dw_w || !dw_b || !gamma) return vv_set_error(VV_E_ARG, "vv_block_mixer: null pointer");
   if (x == out) return vv_set_error(VV_E_ARG, "vv_block_mixer: in-place not allowed (halo rows)");
   if (T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_block_mixer: bad shape");
-  // channel slice: whole rows when C is narrow; otherwise split channels until ~64 blocks exist (rows are few when C is wide)
-  int CS = C;
-  auto tiles_for = [&](int cs) { int tr = 15360 / cs - 6; if (tr > 64) tr = 64; if (tr > T) tr = T; if (tr < 1) tr = 1; return tr; };
-  while (CS > 64 && (CS > 1024 || (long)((T + tiles_for(CS) - 1) / tiles_for(CS)) * ((C + CS - 1) / CS) < 64)) CS = (CS + 1) / 2;
-  const int TR = tiles_for(CS);
+  int CS = 64;                                   // channel slice: power of two <= 64 that covers narrow stages exactly
+  while (CS > 1 && CS / 2 >= C) CS >>= 1;
+  int TR = T < 32 ? T : 32;
   const size_t lds = (size_t)(TR + 6) * CS * sizeof(float);
-  if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: C=%d too wide", C);
   if (hist && TR < 6 && T > TR)   // row tiles 1..5 would read hist while tile 0 rewrites it
     return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: streaming with C=%d needs T<=%d rows per call (got %d)", C, TR, T);
   dim3 grid((T + TR - 1) / TR, (C + CS - 1) / CS);
+  if (grid.y > 65535u || grid.x > 2147483647u) return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: grid too large");
   hipLaunchKernelGGL(block_mixer_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, out, T, C, norm_w, eps,
                      dw_w, dw_b, gamma, hist, TR, CS);
   VV_CHECK_LAUNCH("vv_block_mixer");

@@ -43,10 +43,15 @@ __device__ __forceinline__ void epi1(const vv_lin_args& a, int m, int n, float v
   else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
   if (a.gate) v *= a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n];
   if (a.res) v += a.res[(int64_t)m * a.ldres + n];
-  a.out[(int64_t)m * a.ldo + n] = v;
+  if (a.flags & VV_LIN_OUT_BF16) {
+    const __hip_bfloat16 b = __float2bfloat16(v);
+    reinterpret_cast<bf16_t*>(a.out)[(int64_t)m * a.ldo + n] = *reinterpret_cast<const bf16_t*>(&b);
+  } else {
+    a.out[(int64_t)m * a.ldo + n] = v;
+  }
 }
 
-template <bool DUAL, bool KSPLIT>
+template <bool DUAL, bool KSPLIT, bool XB>
 __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                    // [32][PITCH]
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
   const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
 
   // ---- per-row RMS statistic of the tile (whole K) -------------------------------------------------------------
-  if (a.pro == VV_PRO_RMSNORM) {
+  if (!XB && a.pro == VV_PRO_RMSNORM) {
     const int r = tid >> 3, q = tid & 7;
     float s = 0.f;
     if (m0 + r < M) {
@@ -85,6 +90,26 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
   const bf16_t* xfrag = xs + (lane & 31) * PITCH + hk;
   const bool active = n0 < N;
 
+  if (XB) {
+    // bf16 activations handed over by the producing GEMM: B fragments stream straight from global like the weights,
+    // no LDS image, no barriers
+    if (active) {
+      const bf16_t* xrow = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(m0 + (lane & 31), M - 1) * a.ldx + hk;
+      const int nsteps = K >> 4;
+      int s_begin = 0, s_end = nsteps;
+      if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
+#pragma unroll 8
+      for (int s = s_begin; s < s_end; ++s) {
+        const u32x4 wa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + s * 16));
+        const u32x4 xb = *reinterpret_cast<const u32x4*>(xrow + s * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+        if (DUAL) {
+          const u32x4 wb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + s * 16));
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, xb), acc2, 0, 0, 0);
+        }
+      }
+    }
+  } else
   for (int kc0 = 0; kc0 < K; kc0 += KCH) {
     const int kc = min(KCH, K - kc0);
     __syncthreads();                                                 // rs visible / previous chunk fully consumed
@@ -170,11 +195,11 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
 
 constexpr size_t LDS_BYTES = 32 * PITCH * 2 + 32 * 4 + 64;
 
-template <bool DUAL, bool KSPLIT>
+template <bool DUAL, bool KSPLIT, bool XB>
 int launch(const vv_lin_args& a, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<DUAL, KSPLIT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<DUAL, KSPLIT, XB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma_linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
@@ -182,7 +207,7 @@ int launch(const vv_lin_args& a, hipStream_t s) {
   const int nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
   dim3 grid(KSPLIT ? nblocks : (nblocks + 3) / 4, rtiles);
   if (grid.y > 65535u) return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: m=%d rows exceed one launch (split the call)", a.m);
-  hipLaunchKernelGGL((mfma_linear_kernel<DUAL, KSPLIT>), grid, dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((mfma_linear_kernel<DUAL, KSPLIT, XB>), grid, dim3(256), LDS_BYTES, s, a);
   return 0;
 }
 
@@ -190,8 +215,10 @@ int launch(const vv_lin_args& a, hipStream_t s) {
 
 // 1 = launched, 0 = shape/alignment not covered (caller falls back to the fp32 VALU GEMM), < 0 = error
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
-  if (a.wdt != VV_BF16 || a.m <= 8 || a.k % 16 || a.ldx % 4) return 0;
+  const bool xb = (a.flags & VV_LIN_X_BF16) != 0;
+  if (a.wdt != VV_BF16 || a.m <= 8 || a.k % 16 || a.ldx % (xb ? 8 : 4)) return 0;
   if ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16) || (uintptr_t)a.x % 16) return 0;
+  if (xb && a.pro != VV_PRO_NONE) return vv_set_error(VV_E_ARG, "vv_linear: a bf16 x takes no prologue");
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if ((a.k * 2) % 16) return 0;
   const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
@@ -199,8 +226,13 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   // there are too few 32x32 tiles to fill the chip anyway
   const bool ksplit = a.k >= 512 || ((nblocks * rtiles < 256) && a.k >= 128);
   int rc;
-  if (a.w2) rc = ksplit ? launch<true, true>(a, s) : launch<true, false>(a, s);
-  else rc = ksplit ? launch<false, true>(a, s) : launch<false, false>(a, s);
+  if (xb) {
+    if (a.w2) rc = ksplit ? launch<true, true, true>(a, s) : launch<true, false, true>(a, s);
+    else rc = ksplit ? launch<false, true, true>(a, s) : launch<false, false, true>(a, s);
+  } else {
+    if (a.w2) rc = ksplit ? launch<true, true, false>(a, s) : launch<true, false, false>(a, s);
+    else rc = ksplit ? launch<false, true, false>(a, s) : launch<false, false, false>(a, s);
+  }
   return rc ? rc : 1;
 }
 
@@ -208,7 +240,10 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
 int vv_mfma_gemm_init() {
   hipError_t e;
 #define VV_ATTR(D, S)                                                                                                   \
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                          (int)LDS_BYTES);                                                                                \
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma init: %s", hipGetErrorString(e));                              \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                           (int)LDS_BYTES);                                                                                \
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma init: %s", hipGetErrorString(e));
   VV_ATTR(false, false) VV_ATTR(false, true) VV_ATTR(true, false) VV_ATTR(true, true)

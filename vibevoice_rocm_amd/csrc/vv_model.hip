@@ -225,11 +225,16 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
   for (int j = 0; j < nb; ++j) {
     const vv_block& B = net->blocks[stage][j];
     VV_TRY(vv_block_mixer(cur, other, (int)T, C, B.norm_w, net->eps, B.dw_w, B.dw_b, B.gamma, B.hist, stream));
+    // T > 8 rows on bf16 weights: both FFN linears run on the matrix cores and the 4C-wide hidden activation is handed
+    // over in bf16 (half the bytes, and the second GEMM reads its fragments straight from it: no LDS staging)
+    const bool handoff = net->wdt == VV_BF16 && T > 8 && C % 16 == 0 && ((uintptr_t)B.w1 % 16 == 0) && ((uintptr_t)B.w2 % 16 == 0);
     vv_lin_args a = lin_base(other, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
     a.pro = VV_PRO_RMSNORM; a.norm_w = B.ffn_norm_w; a.eps = net->eps; a.bias = B.b1; a.act = VV_ACT_GELU;
+    if (handoff) a.flags |= VV_LIN_OUT_BF16;
     VV_TRY(vv_linear(&a, stream));
     float* dst = (j == nb - 1 && final_dst) ? final_dst : other;
     a = lin_base(hid, 4 * C, (int)T, B.w2, C, 4 * C, net->wdt, dst, C);
+    if (handoff) a.flags |= VV_LIN_X_BF16;
     a.bias = B.b2; a.gate = B.ffn_gamma; a.gate_ld = 0; a.res = other; a.ldres = C;
     VV_TRY(vv_linear(&a, stream));
     if (dst == other) { float* t = cur; cur = other; other = t; }   // result now in `cur`
