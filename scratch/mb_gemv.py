@@ -2,12 +2,12 @@ import sys, ctypes as C, torch, time
 sys.path.insert(0, "/root/repo")
 from vibevoice_rocm_amd import _lib as L
 lib = L.load()
-def bench(m, n, k, dual, blocks, iters=300, pro=1, mod=True):
+def bench(m, n, k, dual, blocks, iters=300, pro=1, mod=True, flags=0, copies=None):
     x = torch.randn(m, k, device="cuda")
     w = (torch.randn(n, k, device="cuda")/k**0.5).bfloat16()
     w2 = (torch.randn(n, k, device="cuda")/k**0.5).bfloat16()
     # several weight copies to defeat the 256MB infinity cache
-    nb = max(1, int(600e6 // (w.numel()*2*(2 if dual else 1))))
+    nb = copies or max(1, int(600e6 // (w.numel()*2*(2 if dual else 1))))
     ws = [(w.clone(), w2.clone()) for _ in range(nb)]
     nw = torch.ones(k, device="cuda"); sh = torch.zeros(m, k, device="cuda"); sc = torch.zeros(m,k,device="cuda")
     out = torch.zeros(m, n, device="cuda")
@@ -16,6 +16,7 @@ def bench(m, n, k, dual, blocks, iters=300, pro=1, mod=True):
     a.n, a.k, a.wdt = n, k, L.VV_BF16
     a.out, a.ldo = out.data_ptr(), n
     a.pro, a.norm_w, a.eps = pro, nw.data_ptr(), 1e-5
+    a.flags = flags
     if mod: a.mod_shift, a.mod_scale, a.ld_mod = sh.data_ptr(), sc.data_ptr(), k
     if dual: a.act = 2
     lib.vv_tune(b"gemv_blocks", blocks)
@@ -32,14 +33,18 @@ def bench(m, n, k, dual, blocks, iters=300, pro=1, mod=True):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1)*1e3/iters
     byts = n*k*2*(2 if dual else 1)
-    print(f"m={m} n={n} k={k} dual={dual} blocks={blocks:5d}: {us:7.2f} us  {byts/us/1e3:7.1f} GB/s", flush=True)
-for blocks in (0, 128, 256, 288, 384, 512, 576, 1152):
+    print(f"m={m} n={n} k={k} dual={dual} pro={pro} mod={mod} flags={flags} copies={nb} blocks={blocks:5d}: {us:7.2f} us  {byts/us/1e3:7.1f} GB/s", flush=True)
+
+
+for blocks in (0, 256, 288, 384, 512, 576):
     bench(2, 4608, 1536, True, blocks)
-for blocks in (0, 256, 374, 512, 560, 1120):
-    bench(2, 8960, 1536, True, blocks)
+for blocks in (0, 256, 374, 448, 512, 560):
+    bench(2, 8960, 1536, True, blocks, mod=False)
 for blocks in (0, 256, 384, 768):
     bench(2, 1536, 4608, False, blocks, pro=0, mod=False)
 for blocks in (0, 256, 384, 768):
     bench(2, 1536, 8960, False, blocks, pro=0, mod=False)
 for blocks in (0, 128, 256, 512):
     bench(2, 2048, 1536, False, blocks, mod=False)
+for blocks in (0, 256, 512, 1024):
+    bench(1, 8192, 2048, False, blocks, mod=False)

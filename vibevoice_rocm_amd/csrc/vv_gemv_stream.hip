@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
     kval[u] = koff[u] < K;
     if (!kval[u]) koff[u] = 0;                    // any valid address; the activation there is forced to 0
   }
+  const bool reused = (a.flags & VV_LIN_W_REUSED) != 0;
   // the first row group's weight loads are issued before the activation prologue so both latencies overlap
   const int gstride = (KSPLIT == 1) ? gridDim.x * 4 : gridDim.x;
   int g = (KSPLIT == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
@@ -75,12 +76,20 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
       const int n = min(grp * RW + r, N - 1);
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
-        b[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (int64_t)n * K + koff[u]));
-        if (DUAL) b2[r][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W2 + (int64_t)n * K + koff[u]));
+        const u32x4* p1 = reinterpret_cast<const u32x4*>(W + (int64_t)n * K + koff[u]);
+        const u32x4* p2 = reinterpret_cast<const u32x4*>(W2 + (int64_t)n * K + koff[u]);
+        if (reused) {            // weights re-read by the next solver step: leave them in L2 / Infinity Cache
+          b[r][u] = *p1;
+          if (DUAL) b2[r][u] = *p2;
+        } else {                 // streamed once per frame: non-temporal, do not pollute the caches
+          b[r][u] = __builtin_nontemporal_load(p1);
+          if (DUAL) b2[r][u] = __builtin_nontemporal_load(p2);
+        }
       }
     }
   };
   if (g < n_groups) issue(cur, cur2, g);
+  if (g + gstride < n_groups) issue(nxt, nxt2, g + gstride);   // two row groups in flight before the prologue even starts
   float xr[M][KU][8];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -143,7 +152,6 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
   int parity = 0;
   while (g < n_groups) {
     const int gn = g + gstride;
-    if (gn < n_groups) issue(nxt, nxt2, gn);      // next group's bytes are in flight while this one is reduced
     float acc[RW][M], acc2[DUAL ? RW : 1][M];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
@@ -209,18 +217,19 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
 #pragma unroll
       for (int u = 0; u < KU; ++u) { cur[r][u] = nxt[r][u]; if (DUAL) cur2[r][u] = nxt2[r][u]; }
     g = gn;
+    if (g + gstride < n_groups) issue(nxt, nxt2, g + gstride);   // keep two groups in flight
   }
 }
 
 template <int M, bool DUAL, int KSPLIT, int KU>
 void launch_one(const vv_lin_args& a, hipStream_t s) {
-  // persistent grid: as many blocks as can be co-resident (2 per CU for the register-heavy dual kernel, 4 otherwise),
-  // sized so every wave walks the same number of row groups (no half-empty last round)
+  // persistent grid, sized from measurements on MI355X (scratch/mb_gemv.py): ~1.5-2 blocks per CU is the sweet spot for the
+  // wave-per-row layout (more blocks only add prologue copies and a ragged last round), one block per row group when the
+  // block's waves split K
   const int n_groups = (a.n + RW - 1) / RW;
   const int work = (KSPLIT == 1) ? (n_groups + 3) / 4 : n_groups;       // blocks if each wave did exactly one group
-  const int resident = DUAL ? 512 : 1024;
-  const int rounds = (work + resident - 1) / resident;
-  int blocks = (work + rounds - 1) / rounds;
+  const int cap = (KSPLIT == 1) ? (DUAL ? 448 : 512) : 1024;
+  int blocks = work < cap ? work : cap;
   if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
   hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU>), dim3(blocks), dim3(256), 0, s, a, n_groups);
 }

@@ -894,36 +894,48 @@ extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads
 // ---------------------------------------------------------------------------------------------------------------
 // Block1D mixer: out = x + gamma * (dwconv7(RMSNorm_c(x)) + b), channels-last, streaming history of normalised rows
 // ---------------------------------------------------------------------------------------------------------------
+#define MIX_TR 32                      // rows per tile
+#define MIX_OWN ((MIX_TR + 6 + 3) / 4) // rows (incl. the 6-row halo) a lane can own when a wave covers one row per step
 __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C,
                                                           const float* norm_w, float eps, const float* dw_w, const float* dw_b,
                                                           const float* gamma, float* hist, int TR, int CS) {
-  // grid = (row tiles of TR rows, channel slices of CS <= 64 channels).  A lane owns one channel of the slice for the whole
-  // kernel (its norm weight, 7 taps, bias and layer scale sit in registers); the per-row RMS statistic needs the whole row,
-  // so every channel slice recomputes it (wide-C stages have few rows, long-T stages have one slice).
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [TR + 6][CS] normalised rows of this slice
+  // grid = (row tiles of TR rows, channel slices of CS <= 64 channels).  A lane owns one channel of the slice and the rows
+  // {wave*rpw + rl + 4*rpw*i}: everything it needs from memory (its channel's parameters, its x values / history values,
+  // and the full rows for the RMS statistic) is requested in one burst at kernel entry, so the kernel is a single memory
+  // round trip, a barrier, the 7-tap conv out of LDS and the store.
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [TR + 6][CS] normalised rows, then [TR + 6] rstd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t0 = blockIdx.x * TR;
   const int tr = min(TR, T - t0);
+  const int nrow = tr + 6;
   const int c0 = blockIdx.y * CS;
   const int cs = min(CS, C - c0);
-  const int rpw = 64 / CS;                         // rows a wave covers per step in the output phase (CS = 64 or 32 or smaller pow2)
+  const int rpw = 64 / CS;
   const int cl = lane % CS, rl = lane / CS;
   const bool cv = cl < cs;
   const int cg = c0 + (cv ? cl : 0);
-  // parameters of this lane's channel: issued first so their latency overlaps the statistics pass
+  float* rstd_s = sm + (int64_t)(TR + 6) * CS;
   const float nw = norm_w[cg], bb = dw_b[cg], gm = gamma[cg];
   float tap[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) tap[k] = dw_w[cg * 7 + k];
-
-  // rows t0-6 .. t0+tr-1 -> sm rows 0 .. tr+5; each wave keeps 4 rows' statistics in flight at once
-  for (int rb = wave * 4; rb < tr + 6; rb += 16) {
+  // own values: row rr = wave*rpw + rl + 4*rpw*i  (t = t0 - 6 + rr; t < 0 -> history row 6 + t, already normalised)
+  float own[MIX_OWN];
+#pragma unroll
+  for (int i = 0; i < MIX_OWN; ++i) {
+    const int rr = wave * rpw + rl + 4 * rpw * i;
+    const int t = t0 - 6 + rr;
+    own[i] = 0.f;
+    if (rr < nrow && cv) own[i] = (t < 0) ? (hist ? hist[(int64_t)(6 + t) * C + cg] : 0.f) : x[(int64_t)t * C + cg];
+  }
+  // row statistics: a wave keeps 4 rows in flight
+  for (int rb = wave * 4; rb < nrow; rb += 16) {
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int t = t0 - 6 + rb + u;
-      xr[u] = (rb + u < tr + 6 && t >= 0) ? x + (int64_t)t * C : nullptr;
+      xr[u] = (rb + u < nrow && t >= 0) ? x + (int64_t)t * C : nullptr;
     }
     for (int c = lane; c < C; c += 64) {
 #pragma unroll
@@ -931,19 +943,22 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int rr = rb + u;
-      if (rr >= tr + 6) break;
-      const int t = t0 - 6 + rr;
-      float* dst = sm + (int64_t)rr * CS;
-      if (t < 0) {
-        for (int c = lane; c < cs; c += 64) dst[c] = hist ? hist[(int64_t)(6 + t) * C + c0 + c] : 0.f;   // t in [-6,-1] -> hist row 6+t
-      } else {
-        const float rstd = rsqrtf(wave_sum(ss[u]) / (float)C + eps);
-        for (int c = lane; c < cs; c += 64) dst[c] = xr[u][c0 + c] * rstd * norm_w[c0 + c];
-      }
+      const float tot = wave_sum(ss[u]);
+      if (lane == 0 && rb + u < nrow) rstd_s[rb + u] = xr[u] ? rsqrtf(tot / (float)C + eps) : 1.f;   // history rows are stored normalised
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MIX_OWN; ++i) {
+    const int rr = wave * rpw + rl + 4 * rpw * i;
+    if (rr < nrow && cv) {
+      const int t = t0 - 6 + rr;
+      sm[(int64_t)rr * CS + cl] = (t < 0) ? own[i] : own[i] * rstd_s[rr] * nw;
+    }
+  }
+  __syncthreads();
+  // outputs: row tt (sm row tt + 6) is owned by the lane that owns sm row tt + 6: wave/rl pattern shifted by 6 rows, so the
+  // residual x value is re-read from L1/L2 only when the owner differs (cheap: this block has just touched that line)
   for (int tt = wave * rpw + rl; tt < tr; tt += 4 * rpw) {
     if (!cv) continue;
     float s = bb;
@@ -954,8 +969,8 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
   }
   if (hist && blockIdx.x == 0) {
     // new history = last 6 rows of [old history ; normalised x rows], for this block's channel slice.  Row tile 0 is the
-    // only reader of hist (its halo, already in sm rows 0..5 before the barrier above), so it is also the only writer;
-    // rows outside its tile are re-normalised here.
+    // only reader of hist (values captured before the first barrier), so it is also the only writer; rows outside its tile
+    // (T > TR) are re-normalised here.
     for (int j = wave; j < 6; j += 4) {
       const int src = T - 6 + j;             // row of x; negative -> old history row j+T
       float* dst = hist + (int64_t)j * C + c0;
@@ -972,7 +987,6 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
       }
     }
   }
-  (void)nw;
 }
 
 extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const float* norm_w, float eps, const float* dw_w,
@@ -982,8 +996,8 @@ extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const fl
   if (T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_block_mixer: bad shape");
   int CS = 64;                                   // channel slice: power of two <= 64 that covers narrow stages exactly
   while (CS > 1 && CS / 2 >= C) CS >>= 1;
-  int TR = T < 32 ? T : 32;
-  const size_t lds = (size_t)(TR + 6) * CS * sizeof(float);
+  int TR = T < MIX_TR ? T : MIX_TR;
+  const size_t lds = (size_t)((TR + 6) * CS + (TR + 6)) * sizeof(float);
   if (hist && TR < 6 && T > TR)   // row tiles 1..5 would read hist while tile 0 rewrites it
     return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mixer: streaming with C=%d needs T<=%d rows per call (got %d)", C, TR, T);
   dim3 grid((T + TR - 1) / TR, (C + CS - 1) / CS);
