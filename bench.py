@@ -186,7 +186,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("VV_DIST_BACKEND", "nccl")          # "gloo" lets two ranks rehearse on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("VV_ALL_RANKS_ONE_GPU") == "1":
+        local_rank = 0
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
 

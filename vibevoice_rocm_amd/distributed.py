@@ -38,6 +38,13 @@ def _numel(shape) -> int:
     return n
 
 
+_ALIGN = 128     # elements: every tensor starts on a 256-byte boundary of its blob (the kernels want 16-byte aligned rows)
+
+
+def _padded(n: int) -> int:
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
 def _broadcast_flat(flat: torch.Tensor, src: int):
     """In-place broadcast of a 1-D tensor whose length is a multiple of the world size: scatter + all-gather."""
     world = dist.get_world_size()
@@ -57,21 +64,21 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], cfg: VVConfig, d
     mats, vecs = _layout(cfg, dtype)
     out: Dict[str, torch.Tensor] = {}
     for group, gdtype in ((mats, dtype), (vecs, torch.float32)):
-        total = sum(_numel(s) for _, s in group)
-        padded = (total + world - 1) // world * world
+        total = sum(_padded(_numel(s)) for _, s in group)
+        padded = (total + world * _ALIGN - 1) // (world * _ALIGN) * (world * _ALIGN)
         flat = torch.empty(padded, dtype=gdtype, device=device)
         if rank == src:
             off = 0
             for name, shape in group:
                 n = _numel(shape)
                 flat[off: off + n].copy_(sd[name].reshape(-1).to(device=device, dtype=gdtype))
-                off += n
+                off += _padded(n)
         _broadcast_flat(flat, src)
         off = 0
         for name, shape in group:
             n = _numel(shape)
             out[name] = flat[off: off + n].view(shape)
-            off += n
+            off += _padded(n)
     return out
 
 

@@ -56,13 +56,18 @@ class DeviceWeights:
         self._sd = None
 
     # ---- helpers -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _aligned(t: torch.Tensor) -> torch.Tensor:
+        # the streaming / matrix-core kernels need 16-byte aligned rows; a view into a packed blob may not be
+        return t if t.data_ptr() % 256 == 0 else t.clone()
+
     def _mat(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.detach().to(device=self.device, dtype=self.wdtype).contiguous()
+        t = self._aligned(t.detach().to(device=self.device, dtype=self.wdtype).contiguous())
         self._keep.append(t)
         return t
 
     def _vec(self, t: torch.Tensor) -> torch.Tensor:
-        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        t = self._aligned(t.detach().to(device=self.device, dtype=torch.float32).contiguous())
         self._keep.append(t)
         return t
 
