@@ -124,6 +124,36 @@ def roofline_leg(model, wl, cfg_scale, frames=12):
     return ents
 
 
+def first_chunk_leg(model, wl, cfg_scale, runs=5):
+    """p50 latency from generate() entry to the first 3200-sample chunk on the host (voice encode + prefill + 1 frame),
+    through the AudioStreamer path the reference's streaming callers use."""
+    from vibevoice_rocm_amd.streamer import AudioStreamer
+
+    class Timer(AudioStreamer):
+        def __init__(self):
+            super().__init__(batch_size=1)
+            self.t_first = None
+
+        def put(self, audio_chunks, sample_indices):
+            audio_chunks[0].detach().cpu()                     # the chunk is on the host, as a consumer would have it
+            if self.t_first is None:
+                self.t_first = time.perf_counter()
+
+    lat = []
+    for _ in range(runs):
+        st = Timer()
+        forced = [wl["special"]["speech_diffusion"]] * 2 + wl["forced"][-2:]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.generate(input_ids=wl["input_ids"], tokenizer=wl["tok"], cfg_scale=cfg_scale, forced_tokens=forced, noise=wl["noise"],
+                       speech_tensors=wl["speech_tensors"], speech_masks=wl["speech_masks"], speech_input_mask=wl["speech_input_mask"],
+                       speech_noise=wl["speech_noise"], audio_streamer=st, generation_config={"do_sample": False})
+        lat.append(1e3 * (st.t_first - t0))
+    lat.sort()
+    return dict(p50_ms=round(lat[len(lat) // 2], 2), min_ms=round(lat[0], 2), max_ms=round(lat[-1], 2), runs=runs,
+                note="generate() entry -> first 3200-sample chunk on host: voice-prompt encode + LLM prefill + first frame")
+
+
 def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
     """The CPU oracle on a bounded sample of the same workload (kind: port)."""
     from oracle import vv_oracle as O
@@ -268,6 +298,9 @@ def main():
                       "achieved_GBps": round(bpf / s_per_frame / 1e9, 1), "frac_of_hbm_peak": round(bpf / s_per_frame / 1e9 / HBM_PEAK_GBS, 4),
                       "frac_if_head_weights_counted_once": round(bpf_res / s_per_frame / 1e9 / HBM_PEAK_GBS, 4)},
         }
+    if rank == 0:
+        result["first_chunk_latency"] = first_chunk_leg(model, wl, args.cfg_scale)
+        log(f"first-chunk latency p50 {result['first_chunk_latency']['p50_ms']} ms")
     if rank == 0 and not args.no_roofline:
         ents = roofline_leg(model, wl, args.cfg_scale)
         log("roofline leg done")
