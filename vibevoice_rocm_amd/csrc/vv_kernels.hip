@@ -928,7 +928,9 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
     own[i] = 0.f;
     if (rr < nrow && cv) own[i] = (t < 0) ? (hist ? hist[(int64_t)(6 + t) * C + cg] : 0.f) : x[(int64_t)t * C + cg];
   }
-  // row statistics: a wave keeps 4 rows in flight
+  // row statistics: a wave keeps 4 rows in flight, 16-byte loads, loads batched ahead of the adds (an un-unrolled
+  // load->add loop would serialise one L2 round trip per iteration)
+  const bool c4 = (C % 4 == 0);
   for (int rb = wave * 4; rb < nrow; rb += 16) {
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xr[4];
@@ -937,9 +939,21 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
       const int t = t0 - 6 + rb + u;
       xr[u] = (rb + u < nrow && t >= 0) ? x + (int64_t)t * C : nullptr;
     }
-    for (int c = lane; c < C; c += 64) {
+    if (c4) {
+#pragma unroll 4
+      for (int c = lane * 4; c < C; c += 256) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (xr[u]) { const float v = xr[u][c]; ss[u] = fmaf(v, v, ss[u]); }
+        for (int u = 0; u < 4; ++u) if (xr[u]) {
+          const float4 v = *reinterpret_cast<const float4*>(xr[u] + c);
+          ss[u] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int c = lane; c < C; c += 64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (xr[u]) { const float v = xr[u][c]; ss[u] = fmaf(v, v, ss[u]); }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

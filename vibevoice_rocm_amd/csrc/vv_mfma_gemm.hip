@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
     float s = 0.f;
     if (m0 + r < M) {
       const float* xr = a.x + (int64_t)(m0 + r) * a.ldx;
+#pragma unroll 8
       for (int k = q * 4; k < K; k += 32) {
         const float4 v = *reinterpret_cast<const float4*>(xr + k);
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
@@ -119,25 +120,37 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       const bool rv = m0 + r < M;
       const float* xr = a.x + (int64_t)(rv ? m0 + r : 0) * a.ldx + kc0;
       const float rstd = (a.pro == VV_PRO_RMSNORM) ? rs[r] : 1.f;
-      for (int k = q * 4; k < kc; k += 32) {
-        float4 v = rv ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.pro == VV_PRO_RMSNORM) {
-          v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
-          if (a.norm_w) { const float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + kc0 + k); v.x *= w4.x; v.y *= w4.y; v.z *= w4.z; v.w *= w4.w; }
-          if (a.mod_scale && rv) {
-            const int64_t mo = (int64_t)(m0 + r) * a.ld_mod + kc0 + k;
-            v.x = v.x * (1.f + a.mod_scale[mo]) + a.mod_shift[mo];
-            v.y = v.y * (1.f + a.mod_scale[mo + 1]) + a.mod_shift[mo + 1];
-            v.z = v.z * (1.f + a.mod_scale[mo + 2]) + a.mod_shift[mo + 2];
-            v.w = v.w * (1.f + a.mod_scale[mo + 3]) + a.mod_shift[mo + 3];
-          }
-        } else if (a.pro == VV_PRO_SILU) {
-          v.x = silu1(v.x); v.y = silu1(v.y); v.z = silu1(v.z); v.w = silu1(v.w);
+      // loads are issued in batches of 8 ahead of the convert/store so the loop is not one L2 round trip per iteration
+      for (int kb = q * 4; kb < kc; kb += 256) {
+        float4 vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = kb + i * 32;
+          vv[i] = (rv && k < kc) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        uint2 p;
-        p.x = pack2(v.x, v.y);
-        p.y = pack2(v.z, v.w);
-        *reinterpret_cast<uint2*>(xs + r * PITCH + k) = p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = kb + i * 32;
+          if (k >= kc) break;
+          float4 v = vv[i];
+          if (a.pro == VV_PRO_RMSNORM) {
+            v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+            if (a.norm_w) { const float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + kc0 + k); v.x *= w4.x; v.y *= w4.y; v.z *= w4.z; v.w *= w4.w; }
+            if (a.mod_scale && rv) {
+              const int64_t mo = (int64_t)(m0 + r) * a.ld_mod + kc0 + k;
+              v.x = v.x * (1.f + a.mod_scale[mo]) + a.mod_shift[mo];
+              v.y = v.y * (1.f + a.mod_scale[mo + 1]) + a.mod_shift[mo + 1];
+              v.z = v.z * (1.f + a.mod_scale[mo + 2]) + a.mod_shift[mo + 2];
+              v.w = v.w * (1.f + a.mod_scale[mo + 3]) + a.mod_shift[mo + 3];
+            }
+          } else if (a.pro == VV_PRO_SILU) {
+            v.x = silu1(v.x); v.y = silu1(v.y); v.z = silu1(v.z); v.w = silu1(v.w);
+          }
+          uint2 p;
+          p.x = pack2(v.x, v.y);
+          p.y = pack2(v.z, v.w);
+          *reinterpret_cast<uint2*>(xs + r * PITCH + k) = p;
+        }
       }
     }
     __syncthreads();
