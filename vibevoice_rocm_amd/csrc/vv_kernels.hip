@@ -1023,17 +1023,19 @@ extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const fl
 }
 
 // pad[0:ctx] <- state; state <- last ctx rows of [state ; pad[ctx : ctx+T]]   (single block: ctx*C is tiny)
-__global__ __launch_bounds__(256) void conv_ctx_kernel(float* pad, float* state, int ctx, int T, int C) {
+__global__ __launch_bounds__(1024) void conv_ctx_kernel(float* pad, float* state, int ctx, int T, int C) {
   const int n = ctx * C;
+#pragma unroll 8
   for (int i = threadIdx.x; i < n; i += blockDim.x) pad[i] = state[i];
   __syncthreads();
   // virtual sequence V = pad[0 : ctx+T]; new state = V[T : T+ctx]
+#pragma unroll 8
   for (int i = threadIdx.x; i < n; i += blockDim.x) state[i] = pad[(int64_t)T * C + i];
 }
 
 extern "C" int vv_conv_ctx(float* pad, float* state, int ctx, int T, int C, vv_stream_t stream) {
   if (!pad || !state || ctx <= 0 || T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_conv_ctx: bad args");
-  hipLaunchKernelGGL(conv_ctx_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pad, state, ctx, T, C);
+  hipLaunchKernelGGL(conv_ctx_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pad, state, ctx, T, C);
   VV_CHECK_LAUNCH("vv_conv_ctx");
   return 0;
 }

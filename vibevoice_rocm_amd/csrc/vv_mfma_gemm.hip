@@ -99,14 +99,20 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       const int nsteps = K >> 4;
       int s_begin = 0, s_end = nsteps;
       if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
-#pragma unroll 8
-      for (int s = s_begin; s < s_end; ++s) {
-        const u32x4 wa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + s * 16));
-        const u32x4 xb = *reinterpret_cast<const u32x4*>(xrow + s * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
-        if (DUAL) {
-          const u32x4 wb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + s * 16));
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, xb), acc2, 0, 0, 0);
+      for (int sb = s_begin; sb < s_end; sb += 8) {           // 8 k-steps of operands requested before the first MFMA
+        u32x4 wa[8], wb[8], xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int s = min(sb + i, s_end - 1);
+          wa[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + s * 16));
+          if (DUAL) wb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + s * 16));
+          xb[i] = *reinterpret_cast<const u32x4*>(xrow + s * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (sb + i >= s_end) break;
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb[i]), acc, 0, 0, 0);
+          if (DUAL) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xb[i]), acc2, 0, 0, 0);
         }
       }
     }
@@ -158,14 +164,20 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       const int nsteps = kc >> 4;
       int s_begin = 0, s_end = nsteps;
       if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
-#pragma unroll 8
-      for (int s = s_begin; s < s_end; ++s) {
-        const u32x4 wa = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + kc0 + s * 16));
-        const u32x4 xb = *reinterpret_cast<const u32x4*>(xfrag + s * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
-        if (DUAL) {
-          const u32x4 wb = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + kc0 + s * 16));
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, xb), acc2, 0, 0, 0);
+      for (int sb = s_begin; sb < s_end; sb += 8) {           // 8 k-steps of weight fragments requested before the first MFMA
+        u32x4 wa[8], wb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int s = min(sb + i, s_end - 1);
+          wa[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + kc0 + s * 16));
+          if (DUAL) wb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + kc0 + s * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (sb + i >= s_end) break;
+          const u32x4 xb = *reinterpret_cast<const u32x4*>(xfrag + (sb + i) * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+          if (DUAL) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xb), acc2, 0, 0, 0);
         }
       }
     }
