@@ -192,6 +192,14 @@ typedef struct vv_head {
 
 typedef struct vv_dpm_coef { float alpha_s, sigma_s, cx, cd, rinv; int order; } vv_dpm_coef;
 
+/* out[(i*rows_b + j), :] = silu(a[j, :] + b[i, :]): the adaLN input silu(cond_proj(cond) + t_emb(t_i)) for all steps at once */
+int vv_add_rows_silu(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream);
+/* step boundary of the sampler in one launch: x_out = DPM-Solver++/CFG update of (v, x_in, m_in) [v == NULL: x_out = x_in],
+ * m_out = x0 prediction, and h[r, :] = W x_out for r < rows (the next step's noisy_images_proj; W == NULL: skipped).
+ * x_in/x_out and m_in/m_out must be distinct buffers. */
+int vv_dpm_proj(const float* v, int64_t ldv, float cfg_scale, const vv_dpm_coef* coef, const float* x_in, const float* m_in,
+                float* x_out, float* m_out, const void* w, int wdt, int latent, int D, float* h, int64_t ldh, int rows, vv_stream_t stream);
+
 size_t vv_head_ws_bytes(const vv_head* h, int n_steps);
 /* sample_speech_tokens for ONE utterance (modeling_vibevoice_inference.py:695-708) with
  * VibeVoiceDiffusionHead.forward (modular_vibevoice_diffusion_head.py:254-280) and the DPM-Solver++ step

@@ -42,10 +42,9 @@ __device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v,
   a.out[(int64_t)m * a.ldo + n] = v;
 }
 
-constexpr int RW = 2;   // weight rows per wave step
 int g_blocks_override = 0;   // tuning hook (vv_tune)
 
-template <int M, bool DUAL, int KSPLIT, int KU>
+template <int M, bool DUAL, int KSPLIT, int KU, int RW>
 __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
   __shared__ float red[4 * M];
   __shared__ float part[2][4][RW * M * 2];
@@ -221,17 +220,25 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
   }
 }
 
-template <int M, bool DUAL, int KSPLIT, int KU>
-void launch_one(const vv_lin_args& a, hipStream_t s) {
+int g_dual_rw = 1;            // weight rows per wave step for the dual (SwiGLU) kernel: 1 keeps 4 waves/SIMD resident
+
+template <int M, bool DUAL, int KSPLIT, int KU, int RW>
+void launch_rw(const vv_lin_args& a, hipStream_t s) {
   // persistent grid, sized from measurements on MI355X (scratch/mb_gemv.py): ~1.5-2 blocks per CU is the sweet spot for the
   // wave-per-row layout (more blocks only add prologue copies and a ragged last round), one block per row group when the
   // block's waves split K
   const int n_groups = (a.n + RW - 1) / RW;
   const int work = (KSPLIT == 1) ? (n_groups + 3) / 4 : n_groups;       // blocks if each wave did exactly one group
-  const int cap = (KSPLIT == 1) ? (DUAL ? 448 : 512) : 1024;
+  const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : 1024;
   int blocks = work < cap ? work : cap;
   if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
-  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU>), dim3(blocks), dim3(256), 0, s, a, n_groups);
+  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW>), dim3(blocks), dim3(256), 0, s, a, n_groups);
+}
+
+template <int M, bool DUAL, int KSPLIT, int KU>
+void launch_one(const vv_lin_args& a, hipStream_t s) {
+  if (DUAL && g_dual_rw == 1) launch_rw<M, DUAL, KSPLIT, KU, 1>(a, s);
+  else launch_rw<M, DUAL, KSPLIT, KU, 2>(a, s);
 }
 
 template <int M, bool DUAL>
@@ -261,6 +268,7 @@ bool launch_ku(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
 }  // namespace
 
 void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
+void vv_gemv_stream_set_dual_rw(int r) { g_dual_rw = r; }
 
 // returns 1 when the call was launched here, 0 when the shape/alignment is not covered (caller falls back)
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {

@@ -32,8 +32,10 @@ extern "C" const char* vv_last_error(void) { return g_err; }
 extern "C" int vv_abi_version(void) { return 1; }
 extern "C" int vv_init(void) { return vv_mfma_gemm_init(); }
 void vv_gemv_stream_set_blocks(int b);
+void vv_gemv_stream_set_dual_rw(int r);
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
+  if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   return vv_set_error(VV_E_ARG, "vv_tune: unknown key");
 }
 
@@ -1059,6 +1061,16 @@ __global__ void add_rows_kernel(const float* a, int64_t lda, const float* b, int
   const int r = blockIdx.x, i = r / rows_b, j = r - i * rows_b;
   for (int c = threadIdx.x; c < n; c += blockDim.x) out[(int64_t)r * n + c] = a[(int64_t)j * lda + c] + b[(int64_t)i * ldb + c];
 }
+__global__ void add_rows_silu_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n) {
+  const int r = blockIdx.x, i = r / rows_b, j = r - i * rows_b;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) out[(int64_t)r * n + c] = silu_f(a[(int64_t)j * lda + c] + b[(int64_t)i * ldb + c]);
+}
+extern "C" int vv_add_rows_silu(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream) {
+  if (!a || !b || !out || rows <= 0 || rows_b <= 0 || rows % rows_b || n <= 0) return vv_set_error(VV_E_ARG, "vv_add_rows_silu: bad args");
+  hipLaunchKernelGGL(add_rows_silu_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, rows, rows_b, n);
+  VV_CHECK_LAUNCH("vv_add_rows_silu");
+  return 0;
+}
 extern "C" int vv_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream) {
   if (!a || !b || !out || rows <= 0 || rows_b <= 0 || rows % rows_b || n <= 0) return vv_set_error(VV_E_ARG, "vv_add_rows: bad args");
   hipLaunchKernelGGL(add_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, rows, rows_b, n);
@@ -1132,6 +1144,58 @@ extern "C" int vv_dpm_step(const float* v, int64_t ldv, int n_samples, int laten
   hipLaunchKernelGGL(dpm_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, v, ldv, n_samples, latent, cfg_scale,
                      alpha_s, sigma_s, cx, cd, rinv, order, x, m_prev);
   VV_CHECK_LAUNCH("vv_dpm_step");
+  return 0;
+}
+
+// One launch per solver step boundary: the DPM-Solver++/CFG update of the previous step's output fused with the next
+// step's noisy_images_proj (h = Wp x, K = latent = 64): every block recomputes the 64-element x (trivial), block 0 also
+// stores x / x0 for the following step.  x and m_prev are double-buffered (x_in != x_out) so blocks that still read the
+// old values never race with block 0's store.
+template <typename WT>
+__global__ __launch_bounds__(256) void dpm_proj_kernel(const float* v, int64_t ldv, int has_v, float cfg, vv_dpm_coef k,
+                                                       const float* x_in, const float* m_in, float* x_out, float* m_out,
+                                                       const WT* W, int latent, int D, float* h, int64_t ldh, int rows) {
+  extern __shared__ float xs[];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < latent; i += blockDim.x) {
+    float xn = x_in[i];
+    if (has_v) {
+      const float vc = v[i], vu = v[ldv + i];
+      const float eps = vu + cfg * (vc - vu);
+      const float x0 = k.alpha_s * xn - k.sigma_s * eps;
+      float xt = k.cx * xn - k.cd * x0;
+      if (k.order == 2) xt -= 0.5f * k.cd * (k.rinv * (x0 - m_in[i]));
+      xn = xt;
+      if (blockIdx.x == 0) m_out[i] = x0;
+    }
+    xs[i] = xn;
+    if (blockIdx.x == 0) x_out[i] = xn;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + tid;
+  if (n < D && W) {
+    const WT* wr = W + (int64_t)n * latent;
+    float s = 0.f;
+    for (int j = 0; j < latent; ++j) s = fmaf(WL<WT>::load1(wr + j), xs[j], s);
+    for (int r = 0; r < rows; ++r) h[(int64_t)r * ldh + n] = s;
+  }
+}
+
+extern "C" int vv_dpm_proj(const float* v, int64_t ldv, float cfg_scale, const vv_dpm_coef* coef, const float* x_in, const float* m_in,
+                           float* x_out, float* m_out, const void* w, int wdt, int latent, int D, float* h, int64_t ldh, int rows,
+                           vv_stream_t stream) {
+  if (!x_in || !x_out || (v && (!coef || !m_in || !m_out)) || latent <= 0) return vv_set_error(VV_E_ARG, "vv_dpm_proj: bad args");
+  if (x_in == x_out || (v && m_in == m_out)) return vv_set_error(VV_E_ARG, "vv_dpm_proj: x/m buffers must be double-buffered");
+  if (w && (!h || D <= 0 || rows <= 0)) return vv_set_error(VV_E_ARG, "vv_dpm_proj: bad projection args");
+  vv_dpm_coef k;
+  memset(&k, 0, sizeof(k));
+  if (v) k = *coef;
+  const int blocks = w ? (D + 255) / 256 : 1;
+  const size_t lds = (size_t)latent * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (wdt == VV_F32) hipLaunchKernelGGL((dpm_proj_kernel<float>), dim3(blocks), dim3(256), lds, s, v, ldv, v ? 1 : 0, cfg_scale, k, x_in, m_in, x_out, m_out, (const float*)w, latent, D, h, ldh, rows);
+  else hipLaunchKernelGGL((dpm_proj_kernel<bf16_t>), dim3(blocks), dim3(256), lds, s, v, ldv, v ? 1 : 0, cfg_scale, k, x_in, m_in, x_out, m_out, (const bf16_t*)w, latent, D, h, ldh, rows);
+  VV_CHECK_LAUNCH("vv_dpm_proj");
   return 0;
 }
 

@@ -88,15 +88,18 @@ extern "C" size_t vv_head_ws_bytes(const vv_head* h, int n_steps) {
   const size_t R = 2 * (size_t)n_steps > 8 ? 2 * (size_t)n_steps : 8;
   const size_t D = h->D;
   return al(8 * D) /*c0*/ + al(R * D) /*c*/ + (size_t)h->layers * al(R * 3 * D) + al(R * 2 * D) + al(8 * D) /*hcur*/ +
-         al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + al(h->latent) /*x*/ + al(h->latent) /*m_prev*/;
+         al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + 4 * al(h->latent) /*x, x0 history: double-buffered*/;
 }
 
 // shared body: rows R (<= 8), modulation tables mod[l] [*, 3D] / modf [*, 2D] with row offset `mrow`
 static int head_body(const vv_head* h, const float* x, int64_t ldx, int R, float* const* mod, const float* modf, int64_t mrow,
                      float* hcur, float* act, float* v, vv_stream_t stream) {
   const int D = h->D;
-  vv_lin_args a = lin_base(x, ldx, R, h->noisy_proj, D, h->latent, h->wdt, hcur, D);
-  VV_TRY(vv_linear(&a, stream));
+  vv_lin_args a;
+  if (x) {                                   // x == NULL: hcur = noisy_images_proj(x) was already produced (vv_dpm_proj)
+    a = lin_base(x, ldx, R, h->noisy_proj, D, h->latent, h->wdt, hcur, D);
+    VV_TRY(vv_linear(&a, stream));
+  }
   for (int l = 0; l < h->layers; ++l) {
     const vv_head_layer& L = h->layer[l];
     const float* ml = mod[l] + mrow * 3 * D;
@@ -116,15 +119,15 @@ static int head_body(const vv_head* h, const float* x, int64_t ldx, int R, float
   return vv_linear(&a, stream);
 }
 
-static int head_modulations(const vv_head* h, const float* c, int rows, float* const* mod, float* modf, vv_stream_t stream) {
+static int head_modulations(const vv_head* h, const float* c, int rows, float* const* mod, float* modf, bool presilu, vv_stream_t stream) {
   const int D = h->D;
   for (int l = 0; l < h->layers; ++l) {
     vv_lin_args a = lin_base(c, D, rows, h->layer[l].adaln, 3 * D, D, h->wdt, mod[l], 3 * D);
-    a.pro = VV_PRO_SILU;
+    a.pro = presilu ? VV_PRO_NONE : VV_PRO_SILU;
     VV_TRY(vv_linear(&a, stream));
   }
   vv_lin_args a = lin_base(c, D, rows, h->final_adaln, 2 * D, D, h->wdt, modf, 2 * D);
-  a.pro = VV_PRO_SILU;
+  a.pro = presilu ? VV_PRO_NONE : VV_PRO_SILU;
   return vv_linear(&a, stream);
 }
 
@@ -145,7 +148,7 @@ extern "C" int vv_head_forward(const vv_head* h, const float* x, const float* te
   VV_TRY(vv_linear(&a, stream));
   // c[r] = c0[r] + temb_rows[r]: rows_b = R with a single "step" whose b-row is row r -> use add_rows twice-free form
   for (int r = 0; r < R; ++r) VV_TRY(vv_add_rows(c0 + (size_t)r * D, D, temb_rows + (size_t)r * D, D, c + (size_t)r * D, 1, 1, D, stream));
-  VV_TRY(head_modulations(h, c, R, mod, modf, stream));
+  VV_TRY(head_modulations(h, c, R, mod, modf, false, stream));
   return head_body(h, x, h->latent, R, mod, modf, 0, hcur, act, v, stream);
 }
 
@@ -165,23 +168,23 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   float* hcur = cv.take(8 * (size_t)D);
   float* act = cv.take(8 * (size_t)h->ffn);
   float* v = cv.take(8 * (size_t)h->latent);
-  float* x = cv.take(h->latent);
-  float* mprev = cv.take(h->latent);
-  // step-invariant work hoisted out of the loop: cond_proj, c = cond_proj(cond) + t_emb(t_i), all adaLN modulations
+  float* xb[2] = {cv.take(h->latent), cv.take(h->latent)};       // x and x0-history are double-buffered per step
+  float* mb[2] = {cv.take(h->latent), cv.take(h->latent)};
+  // step-invariant work hoisted out of the loop: cond_proj, silu(cond_proj(cond) + t_emb(t_i)), all adaLN modulations
   vv_lin_args a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
   VV_TRY(vv_linear(&a, stream));
-  VV_TRY(vv_add_rows(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
-  VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, stream));
-  hipError_t e = hipMemcpyAsync(x, noise, (size_t)h->latent * 4, hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_sample: %s", hipGetErrorString(e));
-  for (int i = 0; i < n_steps; ++i) {
-    // both rows (cond, uncond) read the same x: ldx = 0
-    VV_TRY(head_body(h, x, 0, 2, mod, modf, 2 * (int64_t)i, hcur, act, v, stream));
-    const vv_dpm_coef& k = coef[i];
-    VV_TRY(vv_dpm_step(v, h->latent, 1, h->latent, cfg_scale, k.alpha_s, k.sigma_s, k.cx, k.cd, k.rinv, k.order, x, mprev, stream));
+  VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+  VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, stream));
+  for (int i = 0; i <= n_steps; ++i) {
+    // step boundary: solver update of the previous step's v (none before step 0) fused with this step's noisy_images_proj
+    const float* xin = (i == 0) ? noise : xb[(i - 1) & 1];
+    float* xout = (i == n_steps) ? latent_out : xb[i & 1];
+    VV_TRY(vv_dpm_proj(i == 0 ? nullptr : v, h->latent, cfg_scale, i == 0 ? nullptr : &coef[i - 1], xin, mb[(i - 1) & 1], xout, mb[i & 1],
+                       i == n_steps ? nullptr : h->noisy_proj, h->wdt, h->latent, D, hcur, D, 2, stream));
+    if (i == n_steps) break;
+    VV_TRY(head_body(h, nullptr, 0, 2, mod, modf, 2 * (int64_t)i, hcur, act, v, stream));
   }
-  e = hipMemcpyAsync(latent_out, x, (size_t)h->latent * 4, hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_sample: %s", hipGetErrorString(e));
+  (void)s;
   return 0;
 }
 
