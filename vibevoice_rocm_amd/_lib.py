@@ -143,6 +143,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (libamdhip64): it must be in the process BEFORE our library is loaded so both
+    # share one runtime instance (loading ours first would bind it to /opt/rocm's copy and split the process in two)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise VVError(f"{LIB_PATH} is missing: build the HIP extension first (python -m vibevoice_rocm_amd.build). "
                       "The MI355X kernels are the only compute path of this package.")
@@ -155,19 +158,8 @@ def load():
         n = lib.vv_sizeof(cname.encode())
         if n != C.sizeof(cls):
             raise VVError(f"ABI mismatch for {cname}: C side {n} bytes, ctypes mirror {C.sizeof(cls)} bytes")
-    rc = lib.vv_init() if _gpu_present() else 0
-    if rc != 0:
-        raise VVError(f"vv_init failed ({rc}): {lib.vv_last_error().decode()}")
     _lib = lib
     return lib
-
-
-def _gpu_present() -> bool:
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
 
 
 def check(rc: int, what: str = ""):

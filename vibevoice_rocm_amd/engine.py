@@ -39,6 +39,8 @@ class Engine:
         self.bf16_t_quirk = (dtype == torch.bfloat16) if bf16_timestep_quirk is None else bf16_timestep_quirk
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.Stream(self.device)
+        torch.zeros(1, device=self.device)              # make sure the HIP context exists before the library touches it
+        L.check(self.lib.vv_init(), "vv_init")          # one-time kernel attributes, before any graph capture
         self.sync_in()
         with torch.cuda.stream(self.stream):
             self.w = DeviceWeights(cfg, state_dict, self.device, dtype)
