@@ -28,8 +28,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KCH = 1024;                 // K elements of the activation tile resident in LDS at a time
-constexpr int PITCH = KCH + 8;            // bf16 elements per LDS row (16-byte pad)
+int g_mt_override = 0;   // tuning hook (vv_tune "mfma_mt")
+
+template <int MT> struct Tile {                 // MT 32-row tiles per workgroup share every weight fragment
+  static constexpr int ROWS = 32 * MT;
+  static constexpr int KCH = 1024 / MT;         // K elements of the activation tile resident in LDS at a time
+  static constexpr int PITCH = KCH + 8;         // bf16 elements per LDS row (16-byte pad -> conflict-free ds_read_b128)
+  static constexpr size_t XS_BYTES = (size_t)ROWS * PITCH * 2;
+  static constexpr size_t RED_BYTES = 4 * 2 * 16 * 64 * 4;
+  static constexpr size_t LDS = (XS_BYTES > RED_BYTES ? XS_BYTES : RED_BYTES) + ROWS * 4 + 64;
+};
 
 __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }
 __device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -51,15 +59,16 @@ __device__ __forceinline__ void epi1(const vv_lin_args& a, int m, int n, float v
   }
 }
 
-template <bool DUAL, bool KSPLIT, bool XB>
+template <bool DUAL, bool KSPLIT, bool XB, int MT>
 __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
+  using T = Tile<MT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                    // [32][PITCH]
-  float* rs = reinterpret_cast<float*>(smem + 32 * PITCH * 2);      // [32] row rstd
-  float* red = reinterpret_cast<float*>(smem);                      // K-split combine scratch (aliases xs after the loop)
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                             // [ROWS][PITCH]
+  float* red = reinterpret_cast<float*>(smem);                                               // K-split combine scratch (aliases xs)
+  float* rs = reinterpret_cast<float*>(smem + (T::XS_BYTES > T::RED_BYTES ? T::XS_BYTES : T::RED_BYTES));   // [ROWS] row rstd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.m, N = a.n, K = a.k;
-  const int m0 = blockIdx.y * 32;
+  const int m0 = blockIdx.y * T::ROWS;
   const int nblk = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
   const int n0 = nblk * 32;
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
@@ -67,95 +76,108 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
 
   // ---- per-row RMS statistic of the tile (whole K) -------------------------------------------------------------
   if (!XB && a.pro == VV_PRO_RMSNORM) {
-    const int r = tid >> 3, q = tid & 7;
-    float s = 0.f;
-    if (m0 + r < M) {
-      const float* xr = a.x + (int64_t)(m0 + r) * a.ldx;
+    const int q = tid & 7;
+    for (int r = tid >> 3; r < T::ROWS; r += 32) {
+      float s = 0.f;
+      if (m0 + r < M) {
+        const float* xr = a.x + (int64_t)(m0 + r) * a.ldx;
 #pragma unroll 8
-      for (int k = q * 4; k < K; k += 32) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + k);
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        for (int k = q * 4; k < K; k += 32) {
+          const float4 v = *reinterpret_cast<const float4*>(xr + k);
+          s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
       }
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      if (q == 0) rs[r] = rsqrtf(s / (float)K + a.eps);
     }
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-    if (q == 0) rs[r] = rsqrtf(s / (float)K + a.eps);
   }
 
-  f32x16 acc, acc2;
+  f32x16 acc[MT], acc2[DUAL ? MT : 1];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[t][i] = 0.f; if (DUAL) acc2[t][i] = 0.f; }
   const int wr = min(n0 + (lane & 31), N - 1);                      // weight row of this lane (clamped; masked at the store)
   const int hk = (lane >> 5) * 8;                                    // k offset of this lane inside a 16-wide step
   const bf16_t* wrow = W + (int64_t)wr * K + hk;
   const bf16_t* wrow2 = DUAL ? (W2 + (int64_t)wr * K + hk) : nullptr;
-  const bf16_t* xfrag = xs + (lane & 31) * PITCH + hk;
+  const bf16_t* xfrag = xs + (lane & 31) * T::PITCH + hk;
   const bool active = n0 < N;
 
   if (XB) {
     // bf16 activations handed over by the producing GEMM: B fragments stream straight from global like the weights,
     // no LDS image, no barriers
     if (active) {
-      const bf16_t* xrow = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(m0 + (lane & 31), M - 1) * a.ldx + hk;
+      const bf16_t* xrow[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xrow[t] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(m0 + 32 * t + (lane & 31), M - 1) * a.ldx + hk;
       const int nsteps = K >> 4;
       int s_begin = 0, s_end = nsteps;
       if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
-      for (int sb = s_begin; sb < s_end; sb += 8) {           // 8 k-steps of operands requested before the first MFMA
-        u32x4 wa[8], wb[8], xb[8];
+      constexpr int UB = (MT == 1) ? 8 : 4;
+      for (int sb = s_begin; sb < s_end; sb += UB) {          // UB k-steps of operands requested before the first MFMA
+        u32x4 wa[UB], wb[DUAL ? UB : 1], xb[UB][MT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < UB; ++i) {
           const int s = min(sb + i, s_end - 1);
           wa[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + s * 16));
           if (DUAL) wb[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow2 + s * 16));
-          xb[i] = *reinterpret_cast<const u32x4*>(xrow + s * 16);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) xb[i][t] = *reinterpret_cast<const u32x4*>(xrow[t] + s * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < UB; ++i) {
           if (sb + i >= s_end) break;
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb[i]), acc, 0, 0, 0);
-          if (DUAL) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xb[i]), acc2, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb[i][t]), acc[t], 0, 0, 0);
+            if (DUAL) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xb[i][t]), acc2[t], 0, 0, 0);
+          }
         }
       }
     }
   } else
-  for (int kc0 = 0; kc0 < K; kc0 += KCH) {
-    const int kc = min(KCH, K - kc0);
+  for (int kc0 = 0; kc0 < K; kc0 += T::KCH) {
+    const int kc = min(T::KCH, K - kc0);
     __syncthreads();                                                 // rs visible / previous chunk fully consumed
-    // ---- stage Xhat[32, kc] ------------------------------------------------------------------------------------
+    // ---- stage Xhat[ROWS, kc] ----------------------------------------------------------------------------------
     {
-      const int r = tid >> 3, q = tid & 7;
-      const bool rv = m0 + r < M;
-      const float* xr = a.x + (int64_t)(rv ? m0 + r : 0) * a.ldx + kc0;
-      const float rstd = (a.pro == VV_PRO_RMSNORM) ? rs[r] : 1.f;
-      // loads are issued in batches of 8 ahead of the convert/store so the loop is not one L2 round trip per iteration
-      for (int kb = q * 4; kb < kc; kb += 256) {
-        float4 vv[8];
+      const int q = tid & 7;
+      for (int r = tid >> 3; r < T::ROWS; r += 32) {
+        const bool rv = m0 + r < M;
+        const float* xr = a.x + (int64_t)(rv ? m0 + r : 0) * a.ldx + kc0;
+        const float rstd = (a.pro == VV_PRO_RMSNORM) ? rs[r] : 1.f;
+        // loads are issued in batches of 8 ahead of the convert/store so the loop is not one L2 round trip per iteration
+        for (int kb = q * 4; kb < kc; kb += 256) {
+          float4 vv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = kb + i * 32;
-          vv[i] = (rv && k < kc) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = kb + i * 32;
-          if (k >= kc) break;
-          float4 v = vv[i];
-          if (a.pro == VV_PRO_RMSNORM) {
-            v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
-            if (a.norm_w) { const float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + kc0 + k); v.x *= w4.x; v.y *= w4.y; v.z *= w4.z; v.w *= w4.w; }
-            if (a.mod_scale && rv) {
-              const int64_t mo = (int64_t)(m0 + r) * a.ld_mod + kc0 + k;
-              v.x = v.x * (1.f + a.mod_scale[mo]) + a.mod_shift[mo];
-              v.y = v.y * (1.f + a.mod_scale[mo + 1]) + a.mod_shift[mo + 1];
-              v.z = v.z * (1.f + a.mod_scale[mo + 2]) + a.mod_shift[mo + 2];
-              v.w = v.w * (1.f + a.mod_scale[mo + 3]) + a.mod_shift[mo + 3];
-            }
-          } else if (a.pro == VV_PRO_SILU) {
-            v.x = silu1(v.x); v.y = silu1(v.y); v.z = silu1(v.z); v.w = silu1(v.w);
+          for (int i = 0; i < 8; ++i) {
+            const int k = kb + i * 32;
+            vv[i] = (rv && k < kc) ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
-          uint2 p;
-          p.x = pack2(v.x, v.y);
-          p.y = pack2(v.z, v.w);
-          *reinterpret_cast<uint2*>(xs + r * PITCH + k) = p;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int k = kb + i * 32;
+            if (k >= kc) break;
+            float4 v = vv[i];
+            if (a.pro == VV_PRO_RMSNORM) {
+              v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+              if (a.norm_w) { const float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + kc0 + k); v.x *= w4.x; v.y *= w4.y; v.z *= w4.z; v.w *= w4.w; }
+              if (a.mod_scale && rv) {
+                const int64_t mo = (int64_t)(m0 + r) * a.ld_mod + kc0 + k;
+                v.x = v.x * (1.f + a.mod_scale[mo]) + a.mod_shift[mo];
+                v.y = v.y * (1.f + a.mod_scale[mo + 1]) + a.mod_shift[mo + 1];
+                v.z = v.z * (1.f + a.mod_scale[mo + 2]) + a.mod_shift[mo + 2];
+                v.w = v.w * (1.f + a.mod_scale[mo + 3]) + a.mod_shift[mo + 3];
+              }
+            } else if (a.pro == VV_PRO_SILU) {
+              v.x = silu1(v.x); v.y = silu1(v.y); v.z = silu1(v.z); v.w = silu1(v.w);
+            }
+            uint2 p;
+            p.x = pack2(v.x, v.y);
+            p.y = pack2(v.z, v.w);
+            *reinterpret_cast<uint2*>(xs + r * T::PITCH + k) = p;
+          }
         }
       }
     }
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       int s_begin = 0, s_end = nsteps;
       if (KSPLIT) { const int per = (nsteps + 3) >> 2; s_begin = wave * per; s_end = min(nsteps, s_begin + per); }
       for (int sb = s_begin; sb < s_end; sb += 8) {           // 8 k-steps of weight fragments requested before the first MFMA
-        u32x4 wa[8], wb[8];
+        u32x4 wa[8], wb[DUAL ? 8 : 1];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int s = min(sb + i, s_end - 1);
@@ -175,9 +197,12 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           if (sb + i >= s_end) break;
-          const u32x4 xb = *reinterpret_cast<const u32x4*>(xfrag + (sb + i) * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
-          if (DUAL) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xb), acc2, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const u32x4 xb = *reinterpret_cast<const u32x4*>(xfrag + t * 32 * T::PITCH + (sb + i) * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, xb), acc[t], 0, 0, 0);
+            if (DUAL) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[i]), __builtin_bit_cast(bf16x8, xb), acc2[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -186,54 +211,65 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
   // ---- epilogue: D[n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][m = lane&31] ----------------------------------------------
   if (!KSPLIT) {
     if (!active) return;
-    const int m = m0 + (lane & 31);
-    if (m >= M) return;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      if (n < N) epi1(a, m, n, acc[reg], DUAL ? acc2[reg] : 0.f);
+    for (int t = 0; t < MT; ++t) {
+      const int m = m0 + 32 * t + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (n < N) epi1(a, m, n, acc[t][reg], DUAL ? acc2[t][reg] : 0.f);
+      }
     }
   } else {
-    __syncthreads();                                                 // xs no longer needed: reuse as red[4][2][16][64]
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      red[((wave * 2 + 0) * 16 + reg) * 64 + lane] = acc[reg];
-      if (DUAL) red[((wave * 2 + 1) * 16 + reg) * 64 + lane] = acc2[reg];
-    }
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
-      const int reg = e >> 6, ln = e & 63;
-      const int m = m0 + (ln & 31);
-      const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
-      if (m < M && n < N) {
-        float v = 0.f, v2 = 0.f;
+    for (int t = 0; t < MT; ++t) {
+      __syncthreads();                                               // xs / previous tile's scratch no longer needed
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) {                             // fixed order: deterministic
-          v += red[((w4 * 2 + 0) * 16 + reg) * 64 + ln];
-          if (DUAL) v2 += red[((w4 * 2 + 1) * 16 + reg) * 64 + ln];
+      for (int reg = 0; reg < 16; ++reg) {
+        red[((wave * 2 + 0) * 16 + reg) * 64 + lane] = acc[t][reg];
+        if (DUAL) red[((wave * 2 + 1) * 16 + reg) * 64 + lane] = acc2[t][reg];
+      }
+      __syncthreads();
+      for (int e = tid; e < 1024; e += 256) {
+        const int reg = e >> 6, ln = e & 63;
+        const int m = m0 + 32 * t + (ln & 31);
+        const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
+        if (m < M && n < N) {
+          float v = 0.f, v2 = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < 4; ++w4) {                           // fixed order: deterministic
+            v += red[((w4 * 2 + 0) * 16 + reg) * 64 + ln];
+            if (DUAL) v2 += red[((w4 * 2 + 1) * 16 + reg) * 64 + ln];
+          }
+          epi1(a, m, n, v, v2);
         }
-        epi1(a, m, n, v, v2);
       }
     }
   }
 }
 
-constexpr size_t LDS_BYTES = 32 * PITCH * 2 + 32 * 4 + 64;
-
-template <bool DUAL, bool KSPLIT, bool XB>
+template <bool DUAL, bool KSPLIT, bool XB, int MT>
 int launch(const vv_lin_args& a, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<DUAL, KSPLIT, XB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<DUAL, KSPLIT, XB, MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tile<MT>::LDS);
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma_linear: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
-  const int nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
+  const int nblocks = (a.n + 31) / 32, rtiles = (a.m + Tile<MT>::ROWS - 1) / Tile<MT>::ROWS;
   dim3 grid(KSPLIT ? nblocks : (nblocks + 3) / 4, rtiles);
   if (grid.y > 65535u) return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: m=%d rows exceed one launch (split the call)", a.m);
-  hipLaunchKernelGGL((mfma_linear_kernel<DUAL, KSPLIT, XB>), grid, dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((mfma_linear_kernel<DUAL, KSPLIT, XB, MT>), grid, dim3(256), Tile<MT>::LDS, s, a);
   return 0;
+}
+
+template <bool DUAL, bool KSPLIT, bool XB>
+int launch_mt(const vv_lin_args& a, hipStream_t s, int mt) {
+  if (mt == 4) return launch<DUAL, KSPLIT, XB, 4>(a, s);
+  if (mt == 2) return launch<DUAL, KSPLIT, XB, 2>(a, s);
+  return launch<DUAL, KSPLIT, XB, 1>(a, s);
 }
 
 }  // namespace
@@ -246,32 +282,38 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (xb && a.pro != VV_PRO_NONE) return vv_set_error(VV_E_ARG, "vv_linear: a bf16 x takes no prologue");
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if ((a.k * 2) % 16) return 0;
-  const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 31) / 32;
+  // rows per workgroup.  MT > 1 (each weight fragment reused by MT 32-row tiles) was measured SLOWER on every shape of this
+  // path on MI355X (19.8 vs 23.4 audio-s/s, first chunk 55 vs 51 ms): these GEMMs are latency bound, and fewer / fatter
+  // workgroups with shorter LDS-resident K chunks cost more than the saved weight re-reads (which hit L2 / Infinity Cache).
+  const int mt = (g_mt_override > 0) ? g_mt_override : 1;
+  const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 32 * mt - 1) / (32 * mt);
   // a wave's K loop is a serial chain of 16-element steps: split K over the workgroup's 4 waves whenever K is long, or when
-  // there are too few 32x32 tiles to fill the chip anyway
+  // there are too few tiles to fill the chip anyway
   const bool ksplit = a.k >= 512 || ((nblocks * rtiles < 256) && a.k >= 128);
   int rc;
   if (xb) {
-    if (a.w2) rc = ksplit ? launch<true, true, true>(a, s) : launch<true, false, true>(a, s);
-    else rc = ksplit ? launch<false, true, true>(a, s) : launch<false, false, true>(a, s);
+    if (a.w2) rc = ksplit ? launch_mt<true, true, true>(a, s, mt) : launch_mt<true, false, true>(a, s, mt);
+    else rc = ksplit ? launch_mt<false, true, true>(a, s, mt) : launch_mt<false, false, true>(a, s, mt);
   } else {
-    if (a.w2) rc = ksplit ? launch<true, true, false>(a, s) : launch<true, false, false>(a, s);
-    else rc = ksplit ? launch<false, true, false>(a, s) : launch<false, false, false>(a, s);
+    if (a.w2) rc = ksplit ? launch_mt<true, true, false>(a, s, mt) : launch_mt<true, false, false>(a, s, mt);
+    else rc = ksplit ? launch_mt<false, true, false>(a, s, mt) : launch_mt<false, false, false>(a, s, mt);
   }
   return rc ? rc : 1;
 }
 
+void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
+
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
 int vv_mfma_gemm_init() {
   hipError_t e;
-#define VV_ATTR(D, S)                                                                                                   \
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          (int)LDS_BYTES);                                                                                \
-  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma init: %s", hipGetErrorString(e));                              \
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                          (int)LDS_BYTES);                                                                                \
+#define VV_ATTR1(D, S, X, MTV)                                                                                           \
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, X, MTV>),                              \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tile<MTV>::LDS);                               \
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "mfma init: %s", hipGetErrorString(e));
+#define VV_ATTR(D, S) VV_ATTR1(D, S, false, 1) VV_ATTR1(D, S, false, 2) VV_ATTR1(D, S, false, 4) \
+                      VV_ATTR1(D, S, true, 1) VV_ATTR1(D, S, true, 2) VV_ATTR1(D, S, true, 4)
   VV_ATTR(false, false) VV_ATTR(false, true) VV_ATTR(true, false) VV_ATTR(true, true)
 #undef VV_ATTR
+#undef VV_ATTR1
   return 0;
 }
