@@ -5,8 +5,9 @@
 // for the whole kernel (prologue = RMSNorm / adaLN modulate / SiLU fused, computed once per wave), and the
 // workgroups are persistent: each wave walks its row groups with the next group's loads already in flight while
 // it reduces the current one (register double buffering), so the memory pipe never drains between rows.
-//   KSPLIT == 1  a wave owns RW whole weight rows per step               (K <= 2560)
-//   KSPLIT == 4  the block's 4 waves split K (interleaved 512-element units) and combine through LDS (long K)
+//   KSPLIT == 1        a wave owns RW whole weight rows per step (block = 4 independent waves)        K <= 2560
+//   KSPLIT == 4/8/16   the block's 4/8/16 waves split K (interleaved 512-element units) and combine through LDS
+//                      in a fixed order (long K: 1.5B down-projections, every 7B matrix)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -45,9 +46,10 @@ __device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v,
 int g_blocks_override = 0;   // tuning hook (vv_tune)
 
 template <int M, bool DUAL, int KSPLIT, int KU, int RW>
-__global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
-  __shared__ float red[4 * M];
-  __shared__ float part[2][4][RW * M * 2];
+__global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
+  constexpr int NW = (KSPLIT == 1) ? 4 : KSPLIT;     // waves per block
+  __shared__ float red[NW * M];
+  __shared__ float part[2][NW][RW * M * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.k, N = a.n, mr = a.m;          // mr <= M real rows
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
   bool kval[KU];
 #pragma unroll
   for (int u = 0; u < KU; ++u) {
-    const int unit = (KSPLIT == 1) ? u : (wave + 4 * u);
+    const int unit = (KSPLIT == 1) ? u : (wave + NW * u);
     koff[u] = unit * 512 + lane * 8;
     kval[u] = koff[u] < K;
     if (!kval[u]) koff[u] = 0;                    // any valid address; the activation there is forced to 0
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
       if (KSPLIT != 1) {
         if (lane == 0) red[wave * M + m] = ss;
         __syncthreads();
-        ss = red[m] + red[M + m] + red[2 * M + m] + red[3 * M + m];
+        ss = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < NW; ++w4) ss += red[w4 * M + m];
       }
       const float rstd = rsqrtf(ss / (float)K + a.eps);
 #pragma unroll
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void gemv_stream_kernel(const vv_lin_args a, c
         if (n < N && m < mr) {
           float s = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int w4 = 0; w4 < 4; ++w4) { s += part[parity][w4][tid * 2]; s2 += part[parity][w4][tid * 2 + 1]; }
+          for (int w4 = 0; w4 < NW; ++w4) { s += part[parity][w4][tid * 2]; s2 += part[parity][w4][tid * 2 + 1]; }
           epi(a, m, n, s, s2);
         }
       }
@@ -232,7 +236,7 @@ void launch_rw(const vv_lin_args& a, hipStream_t s) {
   const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : 1024;
   int blocks = work < cap ? work : cap;
   if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
-  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW>), dim3(blocks), dim3(256), 0, s, a, n_groups);
+  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
 }
 
 template <int M, bool DUAL, int KSPLIT, int KU>
@@ -241,26 +245,25 @@ void launch_one(const vv_lin_args& a, hipStream_t s) {
   else launch_rw<M, DUAL, KSPLIT, KU, 2>(a, s);
 }
 
+template <int M, bool DUAL, int KSPLIT>
+bool launch_kus(const vv_lin_args& a, hipStream_t s, int ku) {
+  switch (ku) {
+    case 1: if constexpr (KSPLIT == 1) { launch_one<M, DUAL, KSPLIT, 1>(a, s); return true; } else return false;
+    case 2: launch_one<M, DUAL, KSPLIT, 2>(a, s); return true;
+    case 3: launch_one<M, DUAL, KSPLIT, 3>(a, s); return true;
+    case 4: if constexpr (!DUAL || KSPLIT == 1) { launch_one<M, DUAL, KSPLIT, 4>(a, s); return true; } else return false;
+    case 5: if constexpr (!DUAL || KSPLIT == 1) { launch_one<M, DUAL, KSPLIT, 5>(a, s); return true; } else return false;
+  }
+  return false;
+}
+
 template <int M, bool DUAL>
 bool launch_ku(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
-  if (ksplit == 1) {
-    switch (ku) {
-      case 1: launch_one<M, DUAL, 1, 1>(a, s); return true;
-      case 2: launch_one<M, DUAL, 1, 2>(a, s); return true;
-      case 3: launch_one<M, DUAL, 1, 3>(a, s); return true;
-      case 4: launch_one<M, DUAL, 1, 4>(a, s); return true;
-      case 5: launch_one<M, DUAL, 1, 5>(a, s); return true;
-    }
-    return false;
-  }
-  if (DUAL) return false;
-  if constexpr (!DUAL) {
-    switch (ku) {
-      case 2: launch_one<M, false, 4, 2>(a, s); return true;
-      case 3: launch_one<M, false, 4, 3>(a, s); return true;
-      case 4: launch_one<M, false, 4, 4>(a, s); return true;
-      case 5: launch_one<M, false, 4, 5>(a, s); return true;
-    }
+  switch (ksplit) {
+    case 1: return launch_kus<M, DUAL, 1>(a, s, ku);
+    case 4: return launch_kus<M, DUAL, 4>(a, s, ku);
+    case 8: return launch_kus<M, DUAL, 8>(a, s, ku);
+    case 16: if constexpr (!DUAL) return launch_kus<M, false, 16>(a, s, ku); else return false;
   }
   return false;
 }
@@ -278,10 +281,19 @@ int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if (a.mod_scale && ((uintptr_t)a.mod_scale % 16 || (uintptr_t)a.mod_shift % 16 || a.ld_mod % 4)) return 0;
   const int units = (a.k + 511) / 512;
-  int ksplit = 1, ku = units;
-  if (units > 5) { ksplit = 4; ku = (units + 3) / 4; }
-  if (ku > 5 || (ksplit == 4 && ku < 2)) return 0;
   const bool dual = a.w2 != nullptr;
+  // smallest wave count whose per-wave slice fits the register-resident activation fragment (KU <= 5 units; <= 3 for the
+  // dual kernel when K is split, its registers hold two weight streams)
+  int ksplit = 1, ku = units;
+  if (units > 5) {
+    const int kumax = dual ? 3 : 5;
+    ksplit = 0;
+    for (int w : {4, 8, 16}) {
+      if ((units + w - 1) / w <= kumax) { ksplit = w; ku = (units + w - 1) / w; break; }
+    }
+    if (!ksplit) return 0;
+    if (ku < 2) ku = 2;
+  }
   bool ok;
   if (a.m == 1) ok = dual ? launch_ku<1, true>(a, s, ksplit, ku) : launch_ku<1, false>(a, s, ksplit, ku);
   else if (a.m == 2) ok = dual ? launch_ku<2, true>(a, s, ksplit, ku) : launch_ku<2, false>(a, s, ksplit, ku);
