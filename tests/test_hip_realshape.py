@@ -173,3 +173,21 @@ def test_batch_of_two_left_padded_matches_single(big):
     assert len(out.speech_outputs) == 2 and out.sequences.shape == (2, 45)
     assert torch.equal(out.speech_outputs[1], one.speech_outputs[0])
     assert out.sequences[1, :15].tolist() == [tok.pad_id] * 15
+
+
+def test_do_sample_constrained_vocabulary(big):
+    """do_sample=True: tokens are drawn only from the constrained set; temperature -> 0 reproduces greedy."""
+    cfg, sd, m = big
+    tok = _Tok(cfg.vocab)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.cat([torch.randint(0, 1000, (30,), generator=g), torch.tensor([tok.speech_start_id])])
+    valid = {tok.speech_start_id, tok.speech_end_id, tok.speech_diffusion_id, tok.eos_token_id}
+    torch.manual_seed(0)
+    out = m.generate(input_ids=ids[None], tokenizer=tok, cfg_scale=1.3, generation_config={"do_sample": True, "temperature": 1.0, "top_p": 0.95},
+                     max_new_tokens=6)
+    assert set(out.sequences[0, 31:].tolist()) <= valid
+    greedy = m.generate(input_ids=ids[None], tokenizer=tok, cfg_scale=1.3, generation_config={"do_sample": False}, max_new_tokens=6,
+                        noise=torch.zeros(6, cfg.latent))
+    cold = m.generate(input_ids=ids[None], tokenizer=tok, cfg_scale=1.3, generation_config={"do_sample": True, "temperature": 1e-4},
+                      max_new_tokens=6, noise=torch.zeros(6, cfg.latent))
+    assert cold.sequences.tolist() == greedy.sequences.tolist()

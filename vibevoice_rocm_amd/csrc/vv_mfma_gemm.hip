@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 int g_mt_override = 0;   // tuning hook (vv_tune "mfma_mt")
+int g_mt_prefill = 2;      // measured on MI355X: 330-token prefill 23.3 ms (MT 1) / 20.7 ms (MT 2) / 30.3 ms (MT 4)
 
 template <int MT> struct Tile {                 // MT 32-row tiles per workgroup share every weight fragment
   static constexpr int ROWS = 32 * MT;
@@ -285,7 +286,9 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   // rows per workgroup.  MT > 1 (each weight fragment reused by MT 32-row tiles) was measured SLOWER on every shape of this
   // path on MI355X (19.8 vs 23.4 audio-s/s, first chunk 55 vs 51 ms): these GEMMs are latency bound, and fewer / fatter
   // workgroups with shorter LDS-resident K chunks cost more than the saved weight re-reads (which hit L2 / Infinity Cache).
-  const int mt = (g_mt_override > 0) ? g_mt_override : 1;
+  // Exception: the prompt prefill (hundreds of rows against the big LLM matrices), where re-reading 55 MB of weights per
+  // 32 rows is the cost.
+  const int mt = (g_mt_override > 0) ? g_mt_override : ((a.m >= 256 && a.k >= 1024 && a.n >= 1024) ? g_mt_prefill : 1);
   const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 32 * mt - 1) / (32 * mt);
   // a wave's K loop is a serial chain of 16-element steps: split K over the workgroup's 4 waves whenever K is long, or when
   // there are too few tiles to fill the chip anyway
@@ -302,6 +305,7 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
 }
 
 void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
+void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; }
 
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
 int vv_mfma_gemm_init() {

@@ -59,6 +59,7 @@ class Engine:
             self.conn_ws = torch.zeros(8 * H, **f32)
             self.logits = torch.zeros(8, **f32)
         self.token_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.logits_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.forced_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()
         self.noise_host = torch.zeros(cfg.latent, dtype=torch.float32).pin_memory()
         self.scheduler = DPMSolverMultistepScheduler(num_train_timesteps=cfg.ddpm_steps, beta_schedule=cfg.beta_schedule,
@@ -201,22 +202,36 @@ class Engine:
             self.hidden2[row].copy_(out[-1])
             self.lens[row] = pos0 + L0
 
-    def _select_token(self):
+    def _logits(self):
         a = L.LinArgs()
         nv = len(self.valid_ids)
         a.x, a.ldx, a.m = self.hidden2.data_ptr(), self.cfg.hidden, 1
         a.w, a.n, a.k, a.wdt = self._w_valid.data_ptr(), nv, self.cfg.hidden, self.w.wdt
         a.out, a.ldo = self.logits.data_ptr(), nv
         self._ck(self.lib.vv_linear(C.byref(a), self.sp), "lm_head")
+
+    def _select_token(self):
+        self._logits()
+        self._pick()
+
+    def _pick(self):
+        nv = len(self.valid_ids)
         self._ck(self.lib.vv_argmax_ids(self.logits.data_ptr(), nv, self._ids_dev.data_ptr(), self.token_dev.data_ptr(),
                                         self.forced_dev.data_ptr(), self.sp), "vv_argmax_ids")
 
     def _seq_A(self, tok_start, tok_diff):
         """batch-2 decode step + token selection + device-side position bookkeeping."""
+        self._seq_A1()
+        self._seq_A2(tok_start, tok_diff)
+
+    def _seq_A1(self):
         self._ck(self.lib.vv_llm_forward(C.byref(self.w.llm), C.byref(self.kv), self.x2.data_ptr(), self.cfg.hidden, 2,
                                          self.lens.data_ptr(), None, self.hidden2.data_ptr(), self.cfg.hidden,
                                          self._llm_ws.data_ptr(), self.sp), "vv_llm_forward")
-        self._select_token()
+        self._logits()
+
+    def _seq_A2(self, tok_start, tok_diff):
+        self._pick()
         self._ck(self.lib.vv_advance_lens(self.lens.data_ptr(), self.token_dev.data_ptr(), tok_start, tok_diff,
                                           self.frame_ctr.data_ptr(), self.sp), "vv_advance_lens")
 
@@ -265,8 +280,25 @@ class Engine:
     # ---------------------------------------------------------------------------------------------------------
     # the three per-token phases used by generate()
     # ---------------------------------------------------------------------------------------------------------
-    def step_decode(self, tok_start: int, tok_diff: int, forced: Optional[int] = None) -> int:
-        """Phase A + the frame's only host sync: returns the chosen token."""
+    def _host_logits(self) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            self.logits_host.copy_(self.logits, non_blocking=True)
+        self.stream.synchronize()
+        return self.logits_host[: len(self.valid_ids)].clone()
+
+    def step_decode(self, tok_start: int, tok_diff: int, forced: Optional[int] = None, sample_fn=None) -> int:
+        """Phase A + the frame's only host sync: returns the chosen token.  With `sample_fn(logits, ids) -> token` (do_sample)
+        the constrained logits are read back first and the sampled token is fed to the device-side bookkeeping."""
+        if sample_fn is not None and forced is None:
+            with torch.cuda.stream(self.stream):
+                self._run("A1", self._seq_A1)
+            tok = int(sample_fn(self._host_logits(), self.valid_ids))
+            with torch.cuda.stream(self.stream):
+                self.forced_host[0] = tok
+                self.forced_dev.copy_(self.forced_host, non_blocking=True)
+                self._run("A2", self._seq_A2, int(tok_start), int(tok_diff))
+            self.stream.synchronize()
+            return tok
         with torch.cuda.stream(self.stream):
             self.forced_host[0] = -1 if forced is None else int(forced)
             self.forced_dev.copy_(self.forced_host, non_blocking=True)
@@ -275,8 +307,12 @@ class Engine:
         self.stream.synchronize()
         return int(self.token_host[0])
 
-    def first_token(self, tok_start: int, tok_diff: int, forced: Optional[int] = None) -> int:
+    def first_token(self, tok_start: int, tok_diff: int, forced: Optional[int] = None, sample_fn=None) -> int:
         """Token selection right after prefill (hidden2[0] already holds the last prompt state)."""
+        if sample_fn is not None and forced is None:
+            with torch.cuda.stream(self.stream):
+                self._logits()
+            forced = int(sample_fn(self._host_logits(), self.valid_ids))
         with torch.cuda.stream(self.stream):
             self.forced_host[0] = -1 if forced is None else int(forced)
             self.forced_dev.copy_(self.forced_host, non_blocking=True)

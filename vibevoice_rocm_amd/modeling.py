@@ -53,6 +53,30 @@ def load_state_dict_from_dir(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def _make_sampler(gen_cfg: dict):
+    """do_sample path (modeling_vibevoice_inference.py:491-494): softmax over the constrained logits + multinomial, with the
+    HF warpers the reference's callers configure (temperature, top_k, top_p; main.py:1187-1196) applied in HF order.
+    Runs on the host over the 4-5 valid logits; draws from torch's CPU generator."""
+    temperature = float(gen_cfg.get("temperature", 1.0) or 1.0)
+    top_k = int(gen_cfg.get("top_k", 0) or 0)
+    top_p = float(gen_cfg.get("top_p", 1.0) or 1.0)
+
+    def sample(logits: torch.Tensor, ids):
+        z = logits.double() / temperature
+        if 0 < top_k < z.numel():
+            kth = torch.topk(z, top_k).values[-1]
+            z = torch.where(z < kth, torch.full_like(z, float("-inf")), z)
+        if top_p < 1.0:
+            sz, order = torch.sort(z, descending=False)
+            cum = torch.softmax(sz, -1).cumsum(-1)
+            remove = cum <= (1 - top_p)
+            remove[-1] = False
+            z[order[remove]] = float("-inf")
+        p = torch.softmax(z, -1)
+        return ids[int(torch.multinomial(p.float(), 1))]
+    return sample
+
+
 class VibeVoiceForConditionalGenerationInference:
     def __init__(self, config: VVConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", torch_dtype=torch.bfloat16,
                  attn_implementation: str = "hip_gfx950", use_graphs: bool = True):
@@ -164,9 +188,7 @@ class VibeVoiceForConditionalGenerationInference:
         if tokenizer is None:
             raise ValueError("generate() needs tokenizer= (for the speech_start/end/diffusion and eos ids)")
         gen_cfg = dict(generation_config or {})
-        if gen_cfg.get("do_sample", False):
-            raise NotImplementedError("do_sample=True (temperature / top-p over the constrained vocabulary) is not built yet; "
-                                      "the reference's default path is greedy")
+        sample_fn = _make_sampler(gen_cfg) if gen_cfg.get("do_sample", False) else None
         verbose = kwargs.get("verbose", False)
         max_length_times = kwargs.get("max_length_times", 2)
         refresh_negative = kwargs.get("refresh_negative", True)
@@ -202,7 +224,7 @@ class VibeVoiceForConditionalGenerationInference:
                     conn_b = conn_all[off: off + n_b]
                     off += n_b
             r = self._generate_one(ids_b, sp_b, conn_b, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
-                                   None if noise is None else torch.as_tensor(noise), audio_streamer, stop_check_fn, b, verbose)
+                                   None if noise is None else torch.as_tensor(noise), audio_streamer, stop_check_fn, b, verbose, sample_fn)
             seqs.append(torch.cat([input_ids[b][~keep], r["sequence"]]))
             audios.append(r["audio"])
             reach.append(r["reach_max"])
@@ -219,7 +241,7 @@ class VibeVoiceForConditionalGenerationInference:
                                          reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
 
     def _generate_one(self, ids: torch.Tensor, sp_mask, conn, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
-                      noise, audio_streamer, stop_check_fn, sample_idx, verbose):
+                      noise, audio_streamer, stop_check_fn, sample_idx, verbose, sample_fn=None):
         eng, cfg = self.engine, self.config
         ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
         valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
@@ -252,12 +274,12 @@ class VibeVoiceForConditionalGenerationInference:
             forced = forced_tokens[step] if (forced_tokens is not None and step < len(forced_tokens)) else None
             if step == 0:
                 eng.prefill(x0, row=0, pos0=0)
-                tok = eng.first_token(ST, SD, forced)
+                tok = eng.first_token(ST, SD, forced, sample_fn)
                 if tok == SD:
                     # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
                     eng.prefill(eng.embed_ids(torch.tensor([ST])), row=1, pos0=0)
             else:
-                tok = eng.step_decode(ST, SD, forced)                                           # :478-496 (+ speculative :581-583)
+                tok = eng.step_decode(ST, SD, forced, sample_fn)                                # :478-496 (+ speculative :581-583)
             seq.append(tok)
             if tok == EOS:                                                                      # :517-526
                 if verbose:
