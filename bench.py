@@ -313,7 +313,7 @@ def main():
                     traffic = json.load(f).get(f"{top['m']}x{top['n']}x{top['k']}")
             except Exception:
                 traffic = None
-        result["roofline"] = {"bound": "hbm", "kernel": f"gemv_kernel m={top['m']} n={top['n']} k={top['k']} dual={top['dual']}",
+        result["roofline"] = {"bound": "hbm", "kernel": f"gemv_stream_kernel (vv_linear m={top['m']} n={top['n']} k={top['k']} dual={top['dual']})",
                               "achieved": round(top["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(top["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                               "avg_us": round(top["avg_us"], 2), "bytes_per_launch": top["weight_bytes"], "launches": top["count"]}
