@@ -134,6 +134,10 @@ int vv_gather_rows(const void* table, int wdt, int64_t hidden, const int* ids_ho
 /* token = ids[argmax logits] (first max in ascending id order, as torch.argmax over the masked vocabulary does,
  * modeling_vibevoice_inference.py:53-66,486-496); *forced_token >= 0 (device int, may be NULL) overrides the choice. */
 int vv_argmax_ids(const float* logits, int n, const int* ids, int* token_out, const int* forced_token, vv_stream_t stream);
+/* out[r, :] = bf16(prologue(x[r, :])) (prologue: VV_PRO_NONE or VV_PRO_RMSNORM with optional weight): the activation operand of a
+ * many-row matrix-core GEMM (vv_linear with VV_LIN_X_BF16), e.g. the prompt prefill */
+int vv_cast_rows_bf16(const float* x, int64_t ldx, int rows, int n, int pro, const float* norm_w, float eps, void* out, int64_t ldo,
+                      vv_stream_t stream);
 int vv_copy_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int n, vv_stream_t stream); /* ldx may be 0 (broadcast) */
 /* one DPM-Solver++ step fused with classifier-free guidance, per latent element
  * (modeling_vibevoice_inference.py:704-707 + vibevoice/schedule/dpm_solver.py:581-584,669-677,738-764):

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "vv_embed_row": (C.c_int, [vp, C.c_int, i64, vp, vp, vp]),
     "vv_gather_rows": (C.c_int, [vp, C.c_int, i64, C.POINTER(C.c_int), C.c_int, vp, vp]),
     "vv_argmax_ids": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "vv_cast_rows_bf16": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, i64, vp]),
     "vv_copy_rows": (C.c_int, [vp, i64, vp, i64, C.c_int, C.c_int, vp]),
     "vv_dpm_step": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                               C.c_float, C.c_int, vp, vp, vp]),

@@ -1220,6 +1220,38 @@ extern "C" int vv_advance_lens(int* lens, const int* token, int tok_start, int t
   return 0;
 }
 
+// rows of prologue(x) rounded to bf16: the activation operand of a matrix-core GEMM whose rows are many (prompt prefill), so
+// the GEMM can stream both operands straight from global without staging.  prologue: RMSNorm (optional weight) or none.
+__global__ __launch_bounds__(256) void cast_rows_bf16_kernel(const float* x, int64_t ldx, const float* norm_w, float eps, int pro, int n,
+                                                             bf16_t* out, int64_t ldo) {
+  __shared__ float red[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (int64_t)r * ldx;
+  float rstd = 1.f;
+  if (pro == VV_PRO_RMSNORM) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int c = tid; c < n; c += 256) { const float v = xr[c]; s = fmaf(v, v, s); }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+  }
+#pragma unroll 4
+  for (int c = tid; c < n; c += 256) {
+    float v = xr[c] * rstd;
+    if (pro == VV_PRO_RMSNORM && norm_w) v *= norm_w[c];
+    kv_store<bf16_t>(out + (int64_t)r * ldo + c, v);
+  }
+}
+extern "C" int vv_cast_rows_bf16(const float* x, int64_t ldx, int rows, int n, int pro, const float* norm_w, float eps, void* out, int64_t ldo,
+                                 vv_stream_t stream) {
+  if (!x || !out || rows <= 0 || n <= 0 || (pro != VV_PRO_NONE && pro != VV_PRO_RMSNORM)) return vv_set_error(VV_E_ARG, "vv_cast_rows_bf16: bad args");
+  hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, norm_w, eps, pro, n, (bf16_t*)out, ldo);
+  VV_CHECK_LAUNCH("vv_cast_rows_bf16");
+  return 0;
+}
+
 __global__ void copy_rows_kernel(const float* x, int64_t ldx, float* out, int64_t ldo, int n) {
   const int r = blockIdx.y;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) out[(int64_t)r * ldo + c] = x[(int64_t)r * ldx + c];

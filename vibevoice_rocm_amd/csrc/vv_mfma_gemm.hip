@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 int g_mt_override = 0;   // tuning hook (vv_tune "mfma_mt")
+int g_mt_prefill_xb = 4;   // bf16 activations streamed from global (no LDS chunks / barriers): 128-row strips
 int g_mt_prefill = 2;      // measured on MI355X: 330-token prefill 23.3 ms (MT 1) / 20.7 ms (MT 2) / 30.3 ms (MT 4)
 
 template <int MT> struct Tile {                 // MT 32-row tiles per workgroup share every weight fragment
@@ -57,6 +58,41 @@ __device__ __forceinline__ void epi1(const vv_lin_args& a, int m, int n, float v
     reinterpret_cast<bf16_t*>(a.out)[(int64_t)m * a.ldo + n] = *reinterpret_cast<const bf16_t*>(&b);
   } else {
     a.out[(int64_t)m * a.ldo + n] = v;
+  }
+}
+
+// four consecutive output channels of one row: 16-byte loads of bias / gate / residual and one 16-byte (fp32) or 8-byte (bf16)
+// store when the row pitches allow it (the accumulator layout gives every lane 4 runs of 4 consecutive channels)
+__device__ __forceinline__ void epi4(const vv_lin_args& a, bool vec_ok, int m, int n, const float (&vin)[4], const float (&v2)[4]) {
+  if (!vec_ok || n + 3 >= a.n) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (n + i < a.n) epi1(a, m, n + i, vin[i], v2[i]);
+    return;
+  }
+  float v[4] = {vin[0], vin[1], vin[2], vin[3]};
+  if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+  if (a.act == VV_ACT_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu1(v[i]);
+  } else if (a.act == VV_ACT_SWIGLU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = silu1(v[i]) * v2[i];
+  }
+  if (a.gate) {
+    const float4 g = *reinterpret_cast<const float4*>(a.gate + (a.gate_ld ? (int64_t)m * a.gate_ld : 0) + n);
+    v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+  }
+  if (a.res) {
+    const float4 r = *reinterpret_cast<const float4*>(a.res + (int64_t)m * a.ldres + n);
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+  }
+  if (a.flags & VV_LIN_OUT_BF16) {
+    uint2 p;
+    p.x = pack2(v[0], v[1]);
+    p.y = pack2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + (int64_t)m * a.ldo + n) = p;
+  } else {
+    *reinterpret_cast<float4*>(a.out + (int64_t)m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -209,7 +245,9 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
     }
   }
 
-  // ---- epilogue: D[n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][m = lane&31] ----------------------------------------------
+  // ---- epilogue: D[n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][m = lane&31]: a lane holds 4 runs of 4 consecutive channels ----
+  const bool vec_ok = (a.ldo % 4 == 0) && ((uintptr_t)a.out % 16 == 0) && (!a.res || (a.ldres % 4 == 0 && (uintptr_t)a.res % 16 == 0)) &&
+                      (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.gate || ((uintptr_t)a.gate % 16 == 0 && a.gate_ld % 4 == 0));
   if (!KSPLIT) {
     if (!active) return;
 #pragma unroll
@@ -217,9 +255,11 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       const int m = m0 + 32 * t + (lane & 31);
       if (m >= M) continue;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (n < N) epi1(a, m, n, acc[t][reg], DUAL ? acc2[t][reg] : 0.f);
+      for (int g = 0; g < 4; ++g) {
+        const float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        float v2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (DUAL) { v2[0] = acc2[t][4 * g]; v2[1] = acc2[t][4 * g + 1]; v2[2] = acc2[t][4 * g + 2]; v2[3] = acc2[t][4 * g + 3]; }
+        epi4(a, vec_ok, m, n0 + 8 * g + 4 * (lane >> 5), v, v2);
       }
     }
   } else {
@@ -232,18 +272,20 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
         if (DUAL) red[((wave * 2 + 1) * 16 + reg) * 64 + lane] = acc2[t][reg];
       }
       __syncthreads();
-      for (int e = tid; e < 1024; e += 256) {
-        const int reg = e >> 6, ln = e & 63;
+      {
+        const int ln = tid & 63, g = tid >> 6;                        // thread -> (accumulator lane, run of 4 registers)
         const int m = m0 + 32 * t + (ln & 31);
-        const int n = n0 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5);
-        if (m < M && n < N) {
-          float v = 0.f, v2 = 0.f;
+        if (m < M) {
+          float v[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int w4 = 0; w4 < 4; ++w4) {                           // fixed order: deterministic
-            v += red[((w4 * 2 + 0) * 16 + reg) * 64 + ln];
-            if (DUAL) v2 += red[((w4 * 2 + 1) * 16 + reg) * 64 + ln];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[i] += red[((w4 * 2 + 0) * 16 + 4 * g + i) * 64 + ln];
+              if (DUAL) v2[i] += red[((w4 * 2 + 1) * 16 + 4 * g + i) * 64 + ln];
+            }
           }
-          epi1(a, m, n, v, v2);
+          epi4(a, vec_ok, m, n0 + 8 * g + 4 * (ln >> 5), v, v2);
         }
       }
     }
@@ -288,7 +330,9 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   // workgroups with shorter LDS-resident K chunks cost more than the saved weight re-reads (which hit L2 / Infinity Cache).
   // Exception: the prompt prefill (hundreds of rows against the big LLM matrices), where re-reading 55 MB of weights per
   // 32 rows is the cost.
-  const int mt = (g_mt_override > 0) ? g_mt_override : ((a.m >= 256 && a.k >= 1024 && a.n >= 1024) ? g_mt_prefill : 1);
+  int mt = 1;
+  if (g_mt_override > 0) mt = g_mt_override;
+  else if (a.m >= 128 && a.k >= 1024 && a.n >= 1024) mt = xb ? g_mt_prefill_xb : g_mt_prefill;
   const long nblocks = (a.n + 31) / 32, rtiles = (a.m + 32 * mt - 1) / (32 * mt);
   // a wave's K loop is a serial chain of 16-element steps: split K over the workgroup's 4 waves whenever K is long, or when
   // there are too few tiles to fill the chip anyway
@@ -305,7 +349,7 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
 }
 
 void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
-void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; }
+void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; g_mt_prefill_xb = mt; }
 
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
 int vv_mfma_gemm_init() {

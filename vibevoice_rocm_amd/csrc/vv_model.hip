@@ -33,11 +33,16 @@ inline vv_lin_args lin_base(const float* x, int64_t ldx, int m, const void* w, i
 // ---------------------------------------------------------------------------------------------------------------
 // Qwen2 decoder stack
 // ---------------------------------------------------------------------------------------------------------------
+// from this many rows on, a bf16-weight LLM forward is a prompt prefill: activations are cast to bf16 once per GEMM and both
+// operands stream from global on the matrix cores with 128-row tiles (every weight fragment reused by 4 row tiles)
+#define VV_PREFILL_ROWS 64
+
 extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   if (!m || R <= 0) return 0;
   const size_t qkv = (size_t)(m->heads + 2 * m->kv_heads) * m->head_dim;
+  const size_t widest = (size_t)(m->inter > m->hidden ? m->inter : m->hidden);
   return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter) +
-         al((size_t)R * m->head_dim);
+         al((size_t)R * m->head_dim) + (R >= VV_PREFILL_ROWS ? al((size_t)R * widest / 2 + 64) : 0);
 }
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
@@ -56,10 +61,19 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   float* rope = c.take((size_t)R * d);
   VV_TRY(vv_copy_rows(x, ldx, h, H, R, H, stream));
   VV_TRY(vv_rope_table(lens, m->inv_freq, R, d, rope, stream));
+  const bool prefill = (R >= VV_PREFILL_ROWS) && m->wdt == VV_BF16 && H % 16 == 0 && m->inter % 16 == 0 && qd % 16 == 0;
+  void* xb = prefill ? (void*)c.take((size_t)R * (m->inter > H ? m->inter : H) / 2 + 64) : nullptr;
   for (int l = 0; l < m->layers; ++l) {
     const vv_llm_layer& L = m->layer[l];
-    vv_lin_args a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
-    a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
+    vv_lin_args a;
+    if (prefill) {
+      VV_TRY(vv_cast_rows_bf16(h, H, R, H, VV_PRO_RMSNORM, L.ln1, m->rms_eps, xb, H, stream));
+      a = lin_base((const float*)xb, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
+      a.flags = VV_LIN_X_BF16; a.bias = L.bqkv;
+    } else {
+      a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
+      a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
+    }
     VV_TRY(vv_linear(&a, stream));
     if (cache_rows == nullptr && R <= kv->rows) {
       VV_TRY(vv_attn_decode(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, stream));   // decode: RoPE + append fused
@@ -67,13 +81,32 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, rope, lens, cache_rows, stream));
       VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
     }
-    a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
+    if (prefill) {
+      VV_TRY(vv_cast_rows_bf16(att, qd, R, qd, VV_PRO_NONE, nullptr, 0.f, xb, qd, stream));
+      a = lin_base((const float*)xb, qd, R, L.wo, H, qd, m->wdt, h, H);
+      a.flags = VV_LIN_X_BF16;
+    } else {
+      a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
+    }
     a.res = h; a.ldres = H;
     VV_TRY(vv_linear(&a, stream));
-    a = lin_base(h, H, R, L.wgate, m->inter, H, m->wdt, act, m->inter);
-    a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln2; a.eps = m->rms_eps; a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
+    if (prefill) {
+      VV_TRY(vv_cast_rows_bf16(h, H, R, H, VV_PRO_RMSNORM, L.ln2, m->rms_eps, xb, H, stream));
+      a = lin_base((const float*)xb, H, R, L.wgate, m->inter, H, m->wdt, act, m->inter);
+      a.flags = VV_LIN_X_BF16;
+    } else {
+      a = lin_base(h, H, R, L.wgate, m->inter, H, m->wdt, act, m->inter);
+      a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln2; a.eps = m->rms_eps;
+    }
+    a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
     VV_TRY(vv_linear(&a, stream));
-    a = lin_base(act, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
+    if (prefill) {
+      VV_TRY(vv_cast_rows_bf16(act, m->inter, R, m->inter, VV_PRO_NONE, nullptr, 0.f, xb, m->inter, stream));
+      a = lin_base((const float*)xb, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
+      a.flags = VV_LIN_X_BF16;
+    } else {
+      a = lin_base(act, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
+    }
     a.res = h; a.ldres = H;
     VV_TRY(vv_linear(&a, stream));
   }
