@@ -1,9 +1,10 @@
 """Multi-GPU sharding of independent dialogues: one process per GPU, one resident replica each,
 no collective inside the generation loop.  Two collectives exist, both outside the per-frame path:
   * `broadcast_state_dict`  rank `src` owns the checkpoint; replicas receive it as two packed blobs (matrices in the
-    weight dtype, vectors in fp32).  Each blob is moved as scatter + all-gather: on a fully connected xGMI node the
-    root pushes 1/N of the blob down each of its links and the peers exchange the pieces over theirs, instead of one
-    ring-bound broadcast (7 links x ~153 GB/s per GPU, point to point).
+    weight dtype, vectors in fp32): two large collectives instead of ~800 small ones.  Default: one RCCL broadcast per
+    blob.  Opt-in (`VV_BCAST=scatter_allgather`): scatter + all-gather, where on a fully connected xGMI node the root
+    pushes 1/N of the blob down each of its links and the peers exchange the pieces over theirs instead of a ring-bound
+    broadcast (7 links x ~153 GB/s per GPU, point to point) - not yet measured on an 8-GPU node, hence not the default.
   * `gather_waveforms`      ragged gather of the generated fp32 waveforms to `dst`.
 The backend is whatever the process group was created with: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 `shard_items` is the dialogue -> rank assignment (dialogue i -> rank i mod world).
@@ -47,8 +48,9 @@ def _padded(n: int) -> int:
 
 def _broadcast_flat(flat: torch.Tensor, src: int):
     """In-place broadcast of a 1-D tensor whose length is a multiple of the world size: scatter + all-gather."""
+    import os
     world = dist.get_world_size()
-    if world <= 2 or dist.get_backend() == "gloo":
+    if world <= 2 or dist.get_backend() == "gloo" or os.environ.get("VV_BCAST", "broadcast") != "scatter_allgather":
         dist.broadcast(flat, src=src)
         return
     chunk = flat.numel() // world
