@@ -37,10 +37,13 @@ def bench(m, n, k, dual, blocks, iters=300, pro=1, mod=True, flags=0, copies=Non
 
 
 
+
 for rw in (2, 1):
-    lib.vv_tune(b"gemv_dual_rw", rw)
-    print("dual rw", rw)
-    for blocks in (0, 384, 512, 768, 1152):
-        bench(2, 4608, 1536, True, blocks)
-    for blocks in (0, 448, 768, 1024, 2240):
-        bench(2, 8960, 1536, True, blocks, mod=False)
+    lib.vv_tune(b"gemv_small_rw", rw)
+    print("small rw", rw)
+    for blocks in (0, 128, 256, 512):
+        bench(2, 2048, 1536, False, blocks, mod=False)
+    for blocks in (0, 192, 384):
+        bench(2, 1536, 1536, False, blocks, pro=0, mod=False)
+    for blocks in (0, 256, 512, 1024):
+        bench(1, 8192, 2048, False, blocks, mod=False)

@@ -228,7 +228,7 @@ int g_dual_rw = 1;            // weight rows per wave step for the dual (SwiGLU)
 
 template <int M, bool DUAL, int KSPLIT, int KU, int RW>
 void launch_rw(const vv_lin_args& a, hipStream_t s) {
-  // persistent grid, sized from measurements on MI355X (scratch/mb_gemv.py): ~1.5-2 blocks per CU is the sweet spot for the
+  // persistent grid, sized from measurements on MI355X (tools/mb_gemv.py): ~1.5-2 blocks per CU is the sweet spot for the
   // wave-per-row layout (more blocks only add prologue copies and a ragged last round), one block per row group when the
   // block's waves split K
   const int n_groups = (a.n + RW - 1) / RW;
@@ -239,9 +239,12 @@ void launch_rw(const vv_lin_args& a, hipStream_t s) {
   hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
 }
 
+int g_small_rw = 2;           // rows per wave step for narrow non-dual matrices (tuning hook)
+
 template <int M, bool DUAL, int KSPLIT, int KU>
 void launch_one(const vv_lin_args& a, hipStream_t s) {
   if (DUAL && g_dual_rw == 1) launch_rw<M, DUAL, KSPLIT, KU, 1>(a, s);
+  else if (!DUAL && KSPLIT == 1 && a.n <= 4096 && g_small_rw == 1) launch_rw<M, DUAL, KSPLIT, KU, 1>(a, s);
   else launch_rw<M, DUAL, KSPLIT, KU, 2>(a, s);
 }
 
@@ -272,6 +275,7 @@ bool launch_ku(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
 
 void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
 void vv_gemv_stream_set_dual_rw(int r) { g_dual_rw = r; }
+void vv_gemv_stream_set_small_rw(int r) { g_small_rw = r; }
 
 // returns 1 when the call was launched here, 0 when the shape/alignment is not covered (caller falls back)
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {

@@ -33,11 +33,13 @@ extern "C" int vv_abi_version(void) { return 1; }
 extern "C" int vv_init(void) { return vv_mfma_gemm_init(); }
 void vv_gemv_stream_set_blocks(int b);
 void vv_gemv_stream_set_dual_rw(int r);
+void vv_gemv_stream_set_small_rw(int r);
 void vv_mfma_set_mt(int mt);
 void vv_mfma_set_mt_prefill(int mt);
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
+  if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
   if (key && !strcmp(key, "mfma_mt")) { vv_mfma_set_mt(value); return 0; }
   if (key && !strcmp(key, "mfma_mt_prefill")) { vv_mfma_set_mt_prefill(value); return 0; }
   return vv_set_error(VV_E_ARG, "vv_tune: unknown key");
