@@ -240,7 +240,7 @@ def main():
     log("weights ready")
     model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
     log(f"engine ready ({model.engine.w.nbytes() / 1e9:.2f} GB resident)")
-    model._bench_sd = sd if (rank == 0 and not args.no_cpu_baseline) else None
+    model._bench_sd = sd if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if model._bench_sd is None:
         del sd
     model.set_ddpm_inference_steps(args.ddpm_steps)
@@ -298,10 +298,11 @@ def main():
                       "achieved_GBps": round(bpf / s_per_frame / 1e9, 1), "frac_of_hbm_peak": round(bpf / s_per_frame / 1e9 / HBM_PEAK_GBS, 4),
                       "frac_if_head_weights_counted_once": round(bpf_res / s_per_frame / 1e9 / HBM_PEAK_GBS, 4)},
         }
-    if rank == 0:
+    single = world == 1            # the diagnostic legs run at N = 1 only (other ranks would just wait at the final barrier)
+    if rank == 0 and single:
         result["first_chunk_latency"] = first_chunk_leg(model, wl, args.cfg_scale)
         log(f"first-chunk latency p50 {result['first_chunk_latency']['p50_ms']} ms")
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and single and not args.no_roofline:
         ents = roofline_leg(model, wl, args.cfg_scale)
         log("roofline leg done")
         top = ents[0]
@@ -318,7 +319,7 @@ def main():
                               "frac": round(top["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                               "avg_us": round(top["avg_us"], 2), "bytes_per_launch": top["weight_bytes"], "launches": top["count"]}
         result["kernels"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in e.items()} for e in ents[:8]]
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and single and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_leg(model, cfg, args.cfg_scale, args.ddpm_steps)
         log("cpu baseline done")
     if rank == 0:
