@@ -154,6 +154,38 @@ def first_chunk_leg(model, wl, cfg_scale, runs=5):
                 note="generate() entry -> first 3200-sample chunk on host: voice-prompt encode + LLM prefill + first frame")
 
 
+def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
+    """Serving-throughput extra (NOT the headline value): `streams` independent dialogues on ONE GPU, each with its own Engine,
+    HIP stream and host thread, sharing the resident weights.  A single dialogue is a latency-bound chain of ~580 small
+    kernels per frame, so a second and third chain fill the bubbles."""
+    import threading
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    models = [model] + [VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
+                        for _ in range(streams - 1)]
+    for mm in models:
+        mm.set_ddpm_inference_steps(args.ddpm_steps)
+    wls = [build_workload(cfg, args.frames, args.voice_frames, seed=101 + i) for i in range(streams)]
+    outs = [0] * streams
+
+    def run(i):
+        outs[i] = run_generate(models[i], wls[i], args.cfg_scale).speech_outputs[0].shape[-1]
+
+    dt = None
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=run, args=(i,)) for i in range(streams)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(streams=streams, value=round(sum(outs) / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3),
+                note="aggregate over independent dialogues run concurrently on one GPU (one Engine/stream/thread each, shared weights); "
+                     "not the headline metric, which is one dialogue per GPU")
+
+
 def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
     """The CPU oracle on a bounded sample of the same workload (kind: port)."""
     from oracle import vv_oracle as O
@@ -205,6 +237,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=3, help="extra leg: N independent dialogues concurrently on one GPU (0/1 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -241,7 +274,8 @@ def main():
     model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
     log(f"engine ready ({model.engine.w.nbytes() / 1e9:.2f} GB resident)")
     model._bench_sd = sd if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    if model._bench_sd is None:
+    model._bench_sd_all = sd if (rank == 0 and world == 1 and args.concurrent > 1) else None
+    if model._bench_sd is None and model._bench_sd_all is None:
         del sd
     model.set_ddpm_inference_steps(args.ddpm_steps)
     wl = build_workload(cfg, args.frames, args.voice_frames, seed=1 + rank)     # every rank its own dialogue
@@ -319,6 +353,9 @@ def main():
                               "frac": round(top["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                               "avg_us": round(top["avg_us"], 2), "bytes_per_launch": top["weight_bytes"], "launches": top["count"]}
         result["kernels"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in e.items()} for e in ents[:8]]
+    if rank == 0 and single and args.concurrent > 1:
+        result["concurrent_streams"] = concurrent_leg(model, cfg, model._bench_sd_all, dtype, device, args, args.concurrent)
+        log(f"concurrent x{args.concurrent}: {result['concurrent_streams']['value']} audio-sec/s aggregate")
     if rank == 0 and single and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_leg(model, cfg, args.cfg_scale, args.ddpm_steps)
         log("cpu baseline done")
