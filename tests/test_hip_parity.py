@@ -148,6 +148,32 @@ def test_linear_fusions(lib, m, n, k, variant, wdtype):
     assert rel_rms(out.cpu().numpy(), ref.numpy()) < tol
 
 
+def test_dpm_step_and_fused_boundary_agree(lib):
+    """vv_dpm_step (stand-alone CFG + DPM-Solver++ update) and vv_dpm_proj (the same update fused with noisy_images_proj) against
+    the closed form, first and second order."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(3)
+    latent, D = 64, 96
+    v = torch.randn(2, latent, generator=g); x = torch.randn(latent, generator=g); mp = torch.randn(latent, generator=g)
+    W = torch.randn(D, latent, generator=g) / 8
+    for order in (1, 2):
+        c = L.DpmCoef(); c.alpha_s, c.sigma_s, c.cx, c.cd, c.rinv, c.order = 0.7, 0.6, 0.9, -0.3, 1.7, order
+        eps = v[1] + 2.0 * (v[0] - v[1])
+        x0 = 0.7 * x - 0.6 * eps
+        ref = 0.9 * x - (-0.3) * x0 - (0.5 * (-0.3) * (1.7 * (x0 - mp)) if order == 2 else 0)
+        vd, xd, md = v.cuda(), x.cuda().clone(), mp.cuda().clone()
+        L.check(l.vv_dpm_step(vd.data_ptr(), latent, 1, latent, 2.0, 0.7, 0.6, 0.9, -0.3, 1.7, order, xd.data_ptr(), md.data_ptr(), None), "dpm_step")
+        xo, mo, h = torch.zeros(latent, device="cuda"), torch.zeros(latent, device="cuda"), torch.zeros(2, D, device="cuda")
+        Wd, xi, mi = W.cuda(), x.cuda(), mp.cuda()
+        L.check(l.vv_dpm_proj(vd.data_ptr(), latent, 2.0, C.byref(c), xi.data_ptr(), mi.data_ptr(), xo.data_ptr(), mo.data_ptr(),
+                              Wd.data_ptr(), L.VV_F32, latent, D, h.data_ptr(), D, 2, None), "dpm_proj")
+        torch.cuda.synchronize()
+        assert rel_rms(xd.cpu().numpy(), ref.numpy()) < 1e-6 and rel_rms(xo.cpu().numpy(), ref.numpy()) < 1e-6
+        assert rel_rms(md.cpu().numpy(), x0.numpy()) < 1e-6 and rel_rms(mo.cpu().numpy(), x0.numpy()) < 1e-6
+        assert rel_rms(h[1].cpu().numpy(), (W @ ref).numpy()) < 1e-5 and torch.equal(h[0], h[1])
+
+
 def test_linear_rejects_bad_args(lib):
     L = lib
     l = L.load()

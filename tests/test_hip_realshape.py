@@ -80,6 +80,39 @@ def test_llm_prefill_and_batch2_decode_1p5b_vs_oracle(big):
     assert rel_rms(eng.hidden2[1].cpu().numpy(), n_ref.numpy()) < 2e-2
 
 
+def test_long_prompt_prefill_path_1p5b_vs_oracle(big):
+    """>= 64 prompt rows take the prefill path (bf16 cast + direct-stream matrix-core GEMMs on 128-row strips, prefill attention
+    over a shared cache row): last hidden state and the cached K/V against the oracle."""
+    from oracle import vv_oracle as O
+    cfg, sd, m = big
+    eng = m.engine
+    W = _cpu(sd, "model.language_model.")
+    ocfg = cfg.as_dict()
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(0, 1000, (150,), generator=g)
+    emb = W["model.language_model.embed_tokens.weight"]
+    kv = O.KVCache(cfg.layers)
+    h_ref = O.llm_forward(W, ocfg, emb[ids], kv, 0)
+    eng.begin_sequence(256, [cfg.vocab - 4, cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1])
+    eng.prefill(eng.embed_ids(ids), row=0)
+    eng.stream.synchronize()
+    assert eng.lens.tolist()[0] == 150
+    assert rel_rms(eng.hidden2[0].cpu().numpy(), h_ref[-1].numpy()) < 2e-2
+    for layer in (0, cfg.layers - 1):
+        k_dev = eng._kv_t[0][layer, 0, :, :150].float().cpu().numpy()
+        v_dev = eng._kv_t[1][layer, 0, :, :150].float().cpu().numpy()
+        assert rel_rms(k_dev, kv.k[layer].numpy()) < 2e-2, layer
+        assert rel_rms(v_dev, kv.v[layer].numpy()) < 2e-2, layer
+    # one decode step on top of the prefilled cache
+    x = 0.05 * torch.randn(1, cfg.hidden, generator=g)
+    p_ref = O.llm_forward(W, ocfg, x, kv, kv.length)[0]
+    with torch.cuda.stream(eng.stream):
+        eng.x2[0].copy_(x[0].cuda()); eng.x2[1].copy_(x[0].cuda())
+        eng.llm_forward(eng.x2, eng.lens, None, eng.hidden2)
+    eng.stream.synchronize()
+    assert rel_rms(eng.hidden2[0].cpu().numpy(), p_ref.numpy()) < 2e-2
+
+
 def test_decoder_and_semantic_frames_1p5b_vs_oracle(big):
     from oracle import vv_oracle as O
     cfg, sd, m = big
