@@ -184,9 +184,11 @@ typedef struct vv_head_layer {
   const void* adaln;  /* [3D, D]: shift | scale | gate */
 } vv_head_layer;
 
+#define VV_HEAD_CHAIN 1 /* vv_head.flags: run the solver loop as ONE persistent chained kernel (vv_chain.hip; experimental, needs the GPU to itself) instead of one launch per GEMV */
 typedef struct vv_head {
   int wdt, D, ffn, layers, latent, cond_dim;
   float eps;
+  int flags;
   const void* noisy_proj;    /* [D, latent] */
   const void* cond_proj;     /* [D, cond_dim] */
   const void* final_adaln;   /* [2D, D]: shift | scale */

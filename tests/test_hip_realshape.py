@@ -48,7 +48,24 @@ def test_head_sampling_1p5b_vs_oracle(big):
         eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(),
                                        eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), eng.sp), "vv_head_sample")
     eng.stream.synchronize()
-    assert rel_rms(eng.latent.cpu().numpy(), ref[0].numpy()) < 2e-2
+    per_gemv = eng.latent.cpu().numpy().copy()
+    assert rel_rms(per_gemv, ref[0].numpy()) < 2e-2
+    # the same solver loop as ONE persistent chained kernel (opt-in, vv_chain.hip): same arithmetic, K-split order differs
+    from vibevoice_rocm_amd import _lib as L
+    eng.w.head.flags = L.VV_HEAD_CHAIN
+    try:
+        with torch.cuda.stream(eng.stream):
+            eng.latent.zero_()
+            for _ in range(3):    # replays start from the previous launch's epochs: the tags/flags must be reset per launch
+                eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(),
+                                               eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), eng.sp), "vv_head_sample")
+        eng.stream.synchronize()
+    finally:
+        eng.w.head.flags = 0
+    chained = eng.latent.cpu().numpy()
+    assert np.isfinite(chained).all()
+    assert rel_rms(chained, per_gemv) < 1e-5
+    assert rel_rms(chained, ref[0].numpy()) < 2e-2
 
 
 def test_llm_prefill_and_batch2_decode_1p5b_vs_oracle(big):

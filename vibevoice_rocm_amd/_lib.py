@@ -16,6 +16,7 @@ VV_F32, VV_BF16 = 0, 1
 PRO_NONE, PRO_RMSNORM, PRO_SILU = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
 LIN_X_BF16, LIN_OUT_BF16, LIN_W_REUSED = 1, 2, 4
+VV_HEAD_CHAIN = 1           # vv_head.flags: solver loop as one persistent chained kernel (opt-in)
 VV_MAX_STAGES = 8
 
 vp = C.c_void_p
@@ -50,7 +51,7 @@ class HeadLayer(C.Structure):
 
 class Head(C.Structure):
     _fields_ = [("wdt", C.c_int), ("D", C.c_int), ("ffn", C.c_int), ("layers", C.c_int), ("latent", C.c_int),
-                ("cond_dim", C.c_int), ("eps", C.c_float), ("noisy_proj", vp), ("cond_proj", vp), ("final_adaln", vp),
+                ("cond_dim", C.c_int), ("eps", C.c_float), ("flags", C.c_int), ("noisy_proj", vp), ("cond_proj", vp), ("final_adaln", vp),
                 ("final_linear", vp), ("layer", C.POINTER(HeadLayer))]
 
 

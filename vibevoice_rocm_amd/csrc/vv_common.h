@@ -23,6 +23,35 @@ int vv_set_error(int code, const char* fmt, ...);
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_stream.hip: 1 = launched, 0 = not covered
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
 int vv_mfma_gemm_init();
+int vv_chain_init();                                              // vv_chain.hip
+int vv_launch_head_chain(const vv_head* h, float* const* mod, const float* modf, const float* noise, const vv_dpm_coef* coef, int n_steps,
+                         float cfg_scale, float* latent_out, float* act, float* const* xb, float* const* mb, float* chain_ws,
+                         hipStream_t s);                         // 1 launched, 0 not covered, <0 error
+size_t vv_head_chain_ws_floats(const vv_head* h);
+void vv_chain_set_blocks(int b);
+void vv_chain_set_dbg_mode(int m);
+void vv_chain_set_dbg(int block, int thread);
+void vv_chain_set_head(int on);
 int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s);
+
+#ifdef __HIPCC__
+// Wave-wide (64 lanes) sum, result in every lane.  DPP row operations reduce each 16-lane row at VALU speed (4 dependent
+// v_add with a DPP operand), the four row sums are combined through readlane.  The usual __shfl_xor butterfly is six
+// dependent ds_bpermute round trips (~100+ cycles each): with one or two waves per SIMD, as in the weight-streaming
+// kernels, that latency sits on the critical path of every row group.  Fixed summation order: deterministic.
+__device__ __forceinline__ float vv_wave_sum(float v) {
+#define VV_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+  VV_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]: lane ^ 1
+  VV_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]: lane ^ 2
+  VV_DPP_ADD(0x141);   // row_half_mirror: the other quad of the 8-lane half row
+  VV_DPP_ADD(0x140);   // row_mirror: the other half of the 16-lane row
+#undef VV_DPP_ADD
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+#endif
 
 #endif

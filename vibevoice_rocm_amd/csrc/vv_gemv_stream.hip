@@ -19,11 +19,7 @@ namespace {
 typedef unsigned short bf16_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wsum(float v) { return vv_wave_sum(v); }   // DPP row reduction, all 64 lanes active
 __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }
 __device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -40,6 +36,26 @@ __device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v,
   else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
   if (a.gate) v *= a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n];
   if (a.res) v += a.res[(int64_t)m * a.ldres + n];
+  a.out[(int64_t)m * a.ldo + n] = v;
+}
+
+// epilogue operands (bias / adaLN gate / residual) of one output: their addresses are known before the dot product is, so
+// they are loaded one row group ahead, in front of the weight loads that follow them in the queue (loads return in order: an
+// operand load issued at epilogue time would sit behind two row groups of prefetched weights)
+struct EpiOp { float b, g, r; };
+__device__ __forceinline__ EpiOp epi_load(const vv_lin_args& a, int m, int n) {
+  EpiOp e;
+  e.b = a.bias ? a.bias[n] : 0.f;
+  e.g = a.gate ? (a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n]) : 1.f;
+  e.r = a.res ? a.res[(int64_t)m * a.ldres + n] : 0.f;
+  return e;
+}
+__device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, float v, float v2, const EpiOp& e) {
+  v += e.b;
+  if (a.act == VV_ACT_GELU) v = gelu1(v);
+  else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
+  if (a.gate) v *= e.g;
+  if (a.res) v += e.r;
   a.out[(int64_t)m * a.ldo + n] = v;
 }
 
@@ -89,8 +105,27 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
       }
     }
   };
-  if (g < n_groups) issue(cur, cur2, g);
-  if (g + gstride < n_groups) issue(nxt, nxt2, g + gstride);   // two row groups in flight before the prologue even starts
+  // epilogue operands: KSPLIT == 1: every lane holds the RW x M entries of its wave's group (uniform addresses, one
+  // request each); K split: thread t < RW M holds the entry it combines
+  constexpr int NE = (KSPLIT == 1) ? RW * M : 1;
+  const bool has_eo = a.bias || a.gate || a.res;
+  EpiOp eo_cur[NE], eo_nxt[NE];
+  auto load_eo = [&](EpiOp (&e)[NE], int grp) {
+    if (!has_eo || grp >= n_groups) return;
+    if (KSPLIT == 1) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) e[r * M + m] = epi_load(a, m < mr ? m : mr - 1, min(grp * RW + r, N - 1));
+    } else if (tid < RW * M) {
+      const int r = tid / M, m = tid - r * M;
+      e[0] = epi_load(a, m < mr ? m : mr - 1, min(grp * RW + r, N - 1));
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NE; ++i) { eo_cur[i].b = 0.f; eo_cur[i].g = 1.f; eo_cur[i].r = 0.f; eo_nxt[i] = eo_cur[i]; }
+  if (g < n_groups) { load_eo(eo_cur, g); issue(cur, cur2, g); }
+  if (g + gstride < n_groups) { load_eo(eo_nxt, g + gstride); issue(nxt, nxt2, g + gstride); }   // two row groups in flight before the prologue even starts
   float xr[M][KU][8];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -188,7 +223,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
           const int n = g * RW + r;
           if (n < N) {
 #pragma unroll
-            for (int m = 0; m < M; ++m) if (m < mr) epi(a, m, n, acc[r][m], DUAL ? acc2[r][m] : 0.f);
+            for (int m = 0; m < M; ++m) if (m < mr) epi_pre(a, m, n, acc[r][m], DUAL ? acc2[r][m] : 0.f, eo_cur[(KSPLIT == 1) ? r * M + m : 0]);
           }
         }
       }
@@ -210,17 +245,19 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
           float s = 0.f, s2 = 0.f;
 #pragma unroll
           for (int w4 = 0; w4 < NW; ++w4) { s += part[parity][w4][tid * 2]; s2 += part[parity][w4][tid * 2 + 1]; }
-          epi(a, m, n, s, s2);
+          epi_pre(a, m, n, s, s2, eo_cur[0]);
         }
       }
       parity ^= 1;                                 // ping-pong: one barrier per group is enough
     }
 #pragma unroll
+    for (int i = 0; i < NE; ++i) eo_cur[i] = eo_nxt[i];
+#pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
       for (int u = 0; u < KU; ++u) { cur[r][u] = nxt[r][u]; if (DUAL) cur2[r][u] = nxt2[r][u]; }
     g = gn;
-    if (g + gstride < n_groups) issue(nxt, nxt2, g + gstride);   // keep two groups in flight
+    if (g + gstride < n_groups) { load_eo(eo_nxt, g + gstride); issue(nxt, nxt2, g + gstride); }   // keep two groups in flight
   }
 }
 

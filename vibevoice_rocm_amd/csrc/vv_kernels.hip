@@ -30,7 +30,10 @@ int vv_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* vv_last_error(void) { return g_err; }
 extern "C" int vv_abi_version(void) { return 1; }
-extern "C" int vv_init(void) { return vv_mfma_gemm_init(); }
+extern "C" int vv_init(void) {
+  VV_TRY(vv_mfma_gemm_init());
+  return vv_chain_init();
+}
 void vv_gemv_stream_set_blocks(int b);
 void vv_gemv_stream_set_dual_rw(int r);
 void vv_gemv_stream_set_small_rw(int r);
@@ -40,6 +43,10 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
+  if (key && !strcmp(key, "chain_blocks")) { vv_chain_set_blocks(value); return 0; }
+  if (key && !strcmp(key, "chain_dbg_mode")) { vv_chain_set_dbg_mode(value); return 0; }
+  if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }
+  if (key && !strcmp(key, "head_chain")) { vv_chain_set_head(value); return 0; }
   if (key && !strcmp(key, "mfma_mt")) { vv_mfma_set_mt(value); return 0; }
   if (key && !strcmp(key, "mfma_mt_prefill")) { vv_mfma_set_mt_prefill(value); return 0; }
   return vv_set_error(VV_E_ARG, "vv_tune: unknown key");

@@ -121,7 +121,8 @@ extern "C" size_t vv_head_ws_bytes(const vv_head* h, int n_steps) {
   const size_t R = 2 * (size_t)n_steps > 8 ? 2 * (size_t)n_steps : 8;
   const size_t D = h->D;
   return al(8 * D) /*c0*/ + al(R * D) /*c*/ + (size_t)h->layers * al(R * 3 * D) + al(R * 2 * D) + al(8 * D) /*hcur*/ +
-         al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + 4 * al(h->latent) /*x, x0 history: double-buffered*/;
+         al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + 4 * al(h->latent) /*x, x0 history: double-buffered*/ +
+         al(vv_head_chain_ws_floats(h)) /*flags + tagged hand-off buffers of the chained kernel*/;
 }
 
 // shared body: rows R (<= 8), modulation tables mod[l] [*, 3D] / modf [*, 2D] with row offset `mrow`
@@ -203,11 +204,16 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   float* v = cv.take(8 * (size_t)h->latent);
   float* xb[2] = {cv.take(h->latent), cv.take(h->latent)};       // x and x0-history are double-buffered per step
   float* mb[2] = {cv.take(h->latent), cv.take(h->latent)};
+  float* chain_ws = cv.take(vv_head_chain_ws_floats(h));
   // step-invariant work hoisted out of the loop: cond_proj, silu(cond_proj(cond) + t_emb(t_i)), all adaLN modulations
   vv_lin_args a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
   VV_TRY(vv_linear(&a, stream));
   VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
   VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, stream));
+  // the whole solver loop as one persistent kernel (vv_chain.hip) when the shapes are covered
+  const int chained = vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
+  if (chained < 0) return chained;
+  if (chained) return 0;
   for (int i = 0; i <= n_steps; ++i) {
     // step boundary: solver update of the previous step's v (none before step 0) fused with this step's noisy_images_proj
     const float* xin = (i == 0) ? noise : xb[(i - 1) & 1];
