@@ -228,6 +228,11 @@ typedef struct vv_block {
   float* hist;                      /* [6, C] streaming state or NULL */
 } vv_block;
 
+/* One whole Block1D (mixer + FFN, vibevoice/modular/modular_vibevoice_tokenizer.py:555-600) as a single launch: x[T, C] -> out[T, C]
+ * (out != x).  Covered: bf16 weights, C = 32 / 64 / 128, T >= 32; anything else returns VV_E_UNSUPPORTED (the composites then
+ * run vv_block_mixer + two vv_linear).  b->hist (or NULL) is the streaming state, updated in place. */
+int vv_block1d(const struct vv_block* b, int wdt, const float* x, float* out, int T, int C, float eps, vv_stream_t stream);
+
 typedef struct vv_conv {
   const void* w;      /* re-laid: SConv1d [cout, kk*cin] with k index = tap*cin + ci;
                          SConvTranspose1d [s*cout, 2*cin] with row = r*cout + co, k = j*cin + ci (j=0: previous input) */

@@ -174,6 +174,53 @@ def test_dpm_step_and_fused_boundary_agree(lib):
         assert rel_rms(h[1].cpu().numpy(), (W @ ref).numpy()) < 1e-5 and torch.equal(h[0], h[1])
 
 
+@pytest.mark.parametrize("C_", [32, 64, 128])
+@pytest.mark.parametrize("T", [32, 45, 800])
+def test_block1d_single_launch_vs_torch(lib, C_, T):
+    """vv_block1d (mixer + FFN of one Block1D in one launch, bf16 weights on the matrix cores) against a torch fp32 restatement
+    of Block1D.forward (modular_vibevoice_tokenizer.py:555-600) on the same bf16-rounded weights; two consecutive streaming calls
+    (history carried in b.hist) and a stateless call.  Tolerance: activations are rounded to bf16 at the two GEMM inputs."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(100 + C_ + T)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    p = dict(gamma=r(C_, sc=0.5), ffn_gamma=r(C_, sc=0.5), norm_w=1 + r(C_, sc=0.1), ffn_norm_w=1 + r(C_, sc=0.1), dw_w=r(C_, 7, sc=0.3), dw_b=r(C_, sc=0.1),
+             w1=(r(4 * C_, C_) / C_ ** 0.5).bfloat16(), b1=r(4 * C_, sc=0.1), w2=(r(C_, 4 * C_) / (4 * C_) ** 0.5).bfloat16(), b2=r(C_, sc=0.1))
+    eps = 1e-5
+
+    def rms(x, w): return x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps) * w
+
+    def ref(x, hist):
+        xn = rms(x, p["norm_w"])
+        seq = torch.cat([hist, xn])
+        s = p["dw_b"] + sum(p["dw_w"][:, k] * seq[k: k + x.shape[0]] for k in range(7))
+        x1 = x + p["gamma"] * s
+        h = torch.nn.functional.gelu(rms(x1, p["ffn_norm_w"]) @ p["w1"].float().T + p["b1"])
+        return x1 + p["ffn_gamma"] * (h @ p["w2"].float().T + p["b2"]), seq[-6:]
+
+    d = {k: v.cuda().contiguous() for k, v in p.items()}
+    hist_dev = torch.zeros(6, C_, device="cuda")
+    b = L.Block()
+    for k in ("gamma", "ffn_gamma", "norm_w", "ffn_norm_w", "dw_w", "dw_b", "w1", "b1", "w2", "b2"):
+        setattr(b, k, d[k].data_ptr())
+    hist = torch.zeros(6, C_)
+    for call in range(3):                       # calls 0, 1: streaming; call 2: stateless (zero left context)
+        x = r(T, C_)
+        streaming = call < 2
+        b.hist = hist_dev.data_ptr() if streaming else None
+        want, new_hist = ref(x, hist if streaming else torch.zeros(6, C_))
+        xd, od = x.cuda(), torch.full((T, C_), float("nan"), device="cuda")
+        L.check(l.vv_block1d(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), T, C_, eps, None), "vv_block1d")
+        torch.cuda.synchronize()
+        assert rel_rms(od.cpu().numpy(), want.numpy()) < 1e-2, (call, C_, T)
+        if streaming:
+            hist = new_hist
+            assert rel_rms(hist_dev.cpu().numpy(), hist.numpy()) < 1e-5, (call, C_, T)
+    # not covered -> explicit refusal, never a silent fallback
+    assert l.vv_block1d(C.byref(b), L.VV_F32, xd.data_ptr(), od.data_ptr(), T, C_, eps, None) != 0
+    assert l.vv_block1d(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), 8, C_, eps, None) != 0
+
+
 def test_linear_rejects_bad_args(lib):
     L = lib
     l = L.load()

@@ -32,6 +32,9 @@ void vv_chain_set_blocks(int b);
 void vv_chain_set_dbg_mode(int m);
 void vv_chain_set_dbg(int block, int thread);
 void vv_chain_set_head(int on);
+int vv_block1d_init();                                            // vv_block1d.hip
+int vv_launch_block1d(const vv_block& B, int wdt, const float* x, float* out, int T, int C, float eps, hipStream_t s);   // 1 launched, 0 not covered
+void vv_block1d_set_fused(int on);
 int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s);
 
 #ifdef __HIPCC__

@@ -32,6 +32,7 @@ extern "C" const char* vv_last_error(void) { return g_err; }
 extern "C" int vv_abi_version(void) { return 1; }
 extern "C" int vv_init(void) {
   VV_TRY(vv_mfma_gemm_init());
+  VV_TRY(vv_block1d_init());
   return vv_chain_init();
 }
 void vv_gemv_stream_set_blocks(int b);
@@ -43,6 +44,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
+  if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "chain_blocks")) { vv_chain_set_blocks(value); return 0; }
   if (key && !strcmp(key, "chain_dbg_mode")) { vv_chain_set_dbg_mode(value); return 0; }
   if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }

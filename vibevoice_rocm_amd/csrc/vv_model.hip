@@ -261,11 +261,28 @@ extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int d
   return 2 * al(a) + al(h);
 }
 
+// Runs the stage's blocks on the ping-pong buffers cur / other.  The LAST block writes its result `nctx` rows into a buffer so
+// that it becomes the next conv's padded input; *pad_out is that buffer.  Unfused block (mixer -> other, lin1 -> hid, lin2): the
+// dead input buffer is the only one free, so the result goes there, shifted.  Fused block (one launch reads its input while
+// other row tiles already write): the result must not overlap the input; `other` is free (no mixer output) and takes it.
 static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*& cur, float*& other, float* hid,
-                      float* final_dst /* or null: leave in a ping-pong buffer */, vv_stream_t stream) {
+                      int nctx, float** pad_out, vv_stream_t stream) {
   const int nb = net->n_blocks[stage];
   for (int j = 0; j < nb; ++j) {
     const vv_block& B = net->blocks[stage][j];
+    const bool last = (j == nb - 1);
+    {   // narrow stages with many rows: the whole block as one launch (vv_block1d.hip)
+      float* dst = last ? other + (size_t)nctx * C : other;
+      const int fused = vv_launch_block1d(B, net->wdt, cur, dst, (int)T, C, net->eps, (hipStream_t)stream);
+      if (fused < 0) return fused;
+      if (fused) {
+        if (last) { *pad_out = other; cur = nullptr; }
+        else { float* t = cur; cur = other; other = t; }
+        continue;
+      }
+    }
+    float* final_dst = last ? cur + (size_t)nctx * C : nullptr;
+    if (last) *pad_out = cur;
     VV_TRY(vv_block_mixer(cur, other, (int)T, C, B.norm_w, net->eps, B.dw_w, B.dw_b, B.gamma, B.hist, stream));
     // T > 8 rows on bf16 weights: both FFN linears run on the matrix cores and the 4C-wide hidden activation is handed
     // over in bf16 (half the bytes, and the second GEMM reads its fragments straight from it: no LDS staging)
@@ -337,13 +354,7 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
       // the last block writes straight into the next conv's padded input; which buffer that is depends on block parity:
       // block j reads cur -> writes other, then they swap.  The last block's mixer output sits in `other_last`, its
       // result may go anywhere except that buffer and hid: use the buffer holding the (dead) input of that block.
-      const int nb = net->n_blocks[i];
-      float* last_in = (nb % 2 == 1) ? cur : other;       // input buffer of the last block
-      float* dst = last_in + (size_t)nctx * C;
-      // dst overlaps last_in shifted by nctx rows; the last block's lin2 reads only hid and the mixer output, so the
-      // dead input buffer can be overwritten.
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, dst, stream));
-      pad = last_in;
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream));
     } else {
       hipError_t e = hipMemcpyAsync(other + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
       if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_decoder_forward: %s", hipGetErrorString(e));
@@ -401,11 +412,7 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
     const vv_conv& nxt = (i + 1 < net->n_stages) ? net->sample[i + 1] : net->head;
     const int nctx = conv_ctx_of(nxt);
     if (net->n_blocks[i] > 0) {
-      const int nb = net->n_blocks[i];
-      float* last_in = (nb % 2 == 1) ? cur : other;
-      float* dst = last_in + (size_t)nctx * C;
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, dst, stream));
-      pad = last_in;
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream));
     } else {
       e = hipMemcpyAsync(other + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, s);
       if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
