@@ -72,7 +72,8 @@ def _ref_linear(x, w, w2, bias, pro, norm_w, eps, shift, scale, act, gate, res):
 @pytest.mark.parametrize("m,n,k", [(1, 1536, 1536), (2, 8960, 1536), (2, 1536, 8960), (2, 64, 1536), (1, 2048, 448),
                                    (8, 4096, 1024), (2, 37, 14), (3, 5, 64), (40, 4608, 1536), (200, 1024, 256),
                                    (3200, 128, 32), (33, 70, 56), (100, 1, 224), (17, 9, 7),
-                                   (2, 3584, 10752), (2, 512, 18944), (1, 256, 24576), (4, 1024, 4096), (7, 640, 2048)])
+                                   (2, 3584, 10752), (2, 512, 18944), (1, 256, 24576), (4, 1024, 4096), (7, 640, 2048),
+                                   (8, 1024, 4096), (8, 1024, 5120), (6, 2560, 2048), (5, 96, 512), (8, 64, 16384)])
 def test_linear_shapes(lib, m, n, k, wdtype):
     L = lib
     l = L.load()
@@ -98,7 +99,7 @@ def test_linear_shapes(lib, m, n, k, wdtype):
 
 
 @pytest.mark.parametrize("wdtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("m,n,k", [(2, 192, 128), (24, 192, 128), (2, 256, 3584), (2, 320, 1536)])
+@pytest.mark.parametrize("m,n,k", [(2, 192, 128), (24, 192, 128), (2, 256, 3584), (2, 320, 1536), (8, 256, 1024), (7, 128, 4096)])
 @pytest.mark.parametrize("variant", ["rms_swiglu", "rms_mod_gate", "silu", "gelu_gamma", "rms_noaffine"])
 def test_linear_fusions(lib, m, n, k, variant, wdtype):
     L = lib

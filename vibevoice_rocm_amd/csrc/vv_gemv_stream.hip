@@ -310,6 +310,20 @@ bool launch_ku(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
   return false;
 }
 
+// 5..8 activation rows (the conv tokenizers' T = 8 stage, C = 1024): the fragment is 8 rows x KU x 8 floats, so K is split
+// until KU <= 2; one pass over the weights instead of two 4-row passes
+bool launch_m8(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
+  if (ksplit == 1) {
+    if (ku == 1) launch_rw<8, false, 1, 1, 1>(a, s); else launch_rw<8, false, 1, 2, 1>(a, s);
+    return true;
+  }
+  switch (ksplit) {
+    case 4: launch_rw<8, false, 4, 2, 2>(a, s); return true;
+    case 8: launch_rw<8, false, 8, 2, 2>(a, s); return true;
+  }
+  return false;   // 16 waves x 8 rows does not fit the 128-VGPR budget of a 1024-thread block: the caller splits the rows
+}
+
 }  // namespace
 
 void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
@@ -318,7 +332,21 @@ void vv_gemv_stream_set_small_rw(int r) { g_small_rw = r; }
 
 // returns 1 when the call was launched here, 0 when the shape/alignment is not covered (caller falls back)
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {
-  if (a.wdt != VV_BF16 || a.m > 4 || a.k % 8) return 0;
+  if (a.wdt != VV_BF16 || a.m > 8 || a.k % 8) return 0;
+  if (a.m > 4) {
+    if (a.w2) return 0;
+    if ((uintptr_t)a.w % 16 || (uintptr_t)a.x % 16 || a.ldx % 4) return 0;
+    if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
+    if (a.mod_scale && ((uintptr_t)a.mod_scale % 16 || (uintptr_t)a.mod_shift % 16 || a.ld_mod % 4)) return 0;
+    const int units8 = (a.k + 511) / 512;
+    int ks = 0, ku8 = 0;
+    for (int w : {1, 4, 8}) {
+      if ((units8 + w - 1) / w <= 2) { ks = w; ku8 = (units8 + w - 1) / w; break; }
+    }
+    if (!ks) return 0;
+    if (ks > 1) ku8 = 2;
+    return launch_m8(a, s, ks, ku8) ? 1 : 0;
+  }
   if ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16) || (uintptr_t)a.x % 16) return 0;
   if (a.m > 1 && a.ldx % 4) return 0;
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;

@@ -474,9 +474,9 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const size_t wsz = sizeof(WT);
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
   if (a.m <= 8) {
-    if (a.m <= 4 && vv_launch_gemv_stream(a, s)) return 0;      // bf16 weight-streaming fast path
+    if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
-      // 5..8 rows: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
+      // 5..8 rows not covered above: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
       vv_lin_args lo = a, hi = a;
       lo.m = 4;
       hi.m = a.m - 4;
