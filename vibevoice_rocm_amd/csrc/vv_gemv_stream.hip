@@ -105,20 +105,17 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
       }
     }
   };
-  // epilogue operands: KSPLIT == 1: every lane holds the RW x M entries of its wave's group (uniform addresses, one
-  // request each); K split: thread t < RW M holds the entry it combines
-  constexpr int NE = (KSPLIT == 1) ? RW * M : 1;
+  // epilogue: output (r, m) of a row group belongs to lane / thread  r * M + m  (KSPLIT == 1: lane of the wave that owns the
+  // group; K split: thread of the block), so activations like GELU run once per output in parallel lanes instead of RW x M
+  // times in lane 0, and each owner fetches its own operands one group ahead
+  constexpr int NE = 1;
   const bool has_eo = a.bias || a.gate || a.res;
+  const int eid = (KSPLIT == 1) ? lane : tid;
   EpiOp eo_cur[NE], eo_nxt[NE];
   auto load_eo = [&](EpiOp (&e)[NE], int grp) {
     if (!has_eo || grp >= n_groups) return;
-    if (KSPLIT == 1) {
-#pragma unroll
-      for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int m = 0; m < M; ++m) e[r * M + m] = epi_load(a, m < mr ? m : mr - 1, min(grp * RW + r, N - 1));
-    } else if (tid < RW * M) {
-      const int r = tid / M, m = tid - r * M;
+    if (eid < RW * M) {
+      const int r = eid / M, m = eid - r * M;
       e[0] = epi_load(a, m < mr ? m : mr - 1, min(grp * RW + r, N - 1));
     }
   };
@@ -217,15 +214,16 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
 #pragma unroll
       for (int m = 0; m < M; ++m) { acc[r][m] = wsum(acc[r][m]); if (DUAL) acc2[r][m] = wsum(acc2[r][m]); }
     if (KSPLIT == 1) {
-      if (lane == 0) {
+      if (lane < RW * M) {                         // every lane holds all sums: lane r * M + m keeps (r, m)
+        float v = acc[0][0], v2 = DUAL ? acc2[0][0] : 0.f;
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-          const int n = g * RW + r;
-          if (n < N) {
+        for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int m = 0; m < M; ++m) if (m < mr) epi_pre(a, m, n, acc[r][m], DUAL ? acc2[r][m] : 0.f, eo_cur[(KSPLIT == 1) ? r * M + m : 0]);
-          }
-        }
+          for (int m = 0; m < M; ++m)
+            if (lane == r * M + m) { v = acc[r][m]; if (DUAL) v2 = acc2[r][m]; }
+        const int r = lane / M, m = lane - r * M;
+        const int n = g * RW + r;
+        if (n < N && m < mr) epi_pre(a, m, n, v, v2, eo_cur[0]);
       }
     } else {
       if (lane == 0) {
