@@ -674,6 +674,30 @@ __device__ __forceinline__ void load_epl(const KT* p, float (&o)[EPL]) {
   else WL<KT>::load4(p, o);
 }
 
+typedef unsigned int att_raw __attribute__((ext_vector_type(4)));     // 16 bytes of cache per lane: 8 bf16 or 4 fp32
+template <typename KT, int EPL>
+__device__ __forceinline__ void unpack_epl(const att_raw v, float (&o)[EPL]) {
+  if constexpr (EPL == 8) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  } else {
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+  }
+}
+// sum over the G lanes that share a key (G = 16: one DPP row, four VALU-speed steps instead of four ds_bpermute round trips)
+__device__ __forceinline__ float group_dot_sum(float v, int G) {
+  if (G == 16) {
+#define VV_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+    VV_DPP_ADD(0xB1); VV_DPP_ADD(0x4E); VV_DPP_ADD(0x141); VV_DPP_ADD(0x140);
+#undef VV_DPP_ADD
+    return v;
+  }
+  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 // One block per (query row, q head).  G lanes share one key (G * EPL == head_dim, EPL = 16 B of cache per lane),
 // so a wave covers 64/G keys per step with fully coalesced 16-byte loads; online softmax per lane group,
 // groups merged through LDS at the end.
@@ -790,8 +814,23 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(const float* qkv, int6
   const KT* vc = vcw;
   const float scale = rsqrtf((float)d);
   const float* row = qkv + (int64_t)r * ld;
-  // rotate this lane's slice of q and of the new k (half rotation: pair (i, i + d/2))
   const int e0 = gl * EPL;
+  // The cached keys / values do not depend on this step's q: the first batch (ATT_UNR keys per lane group, raw 16-byte slices)
+  // is requested before q, the new k and the RoPE table are even loaded, and batch i+1 is requested before batch i is used.
+  const int stride = NW * KPW * ATT_UNR;
+  att_raw kraw[2][ATT_UNR], vraw[2][ATT_UNR];
+  auto issue_kv = [&](int buf, int s0) {
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      const int sidx = s0 + u * KPW + gi;
+      const int sc = sidx < pos ? sidx : 0;
+      kraw[buf][u] = *reinterpret_cast<const att_raw*>(kc + (int64_t)sc * d + e0);
+      vraw[buf][u] = *reinterpret_cast<const att_raw*>(vc + (int64_t)sc * d + e0);
+    }
+  };
+  const int s_first = (wave * ATT_UNR) * KPW;
+  if (s_first < pos) issue_kv(0, s_first);
+  // rotate this lane's slice of q and of the new k (half rotation: pair (i, i + d/2))
   const bool lo = e0 < half;
   const int pe0 = lo ? e0 + half : e0 - half;
   float q[EPL], kn[EPL], vn[EPL];
@@ -830,32 +869,31 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(const float* qkv, int6
     for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vx[j], acc[j] * corr);
     mmax = mn;
   };
-  const int stride = NW * KPW * ATT_UNR;
-  for (int s0 = (wave * ATT_UNR) * KPW; s0 < pos; s0 += stride) {
-    float kx[ATT_UNR][EPL], vx[ATT_UNR][EPL];
-    bool valid[ATT_UNR];
+  auto consume = [&](int buf, int s0) {
 #pragma unroll
     for (int u = 0; u < ATT_UNR; ++u) {
-      const int s = s0 + u * KPW + gi;
-      valid[u] = s < pos;
-      const int sc = valid[u] ? s : 0;
-      load_epl<KT, EPL>(kc + (int64_t)sc * d + e0, kx[u]);
-      load_epl<KT, EPL>(vc + (int64_t)sc * d + e0, vx[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < ATT_UNR; ++u) {
+      float kx[EPL], vx[EPL];
+      unpack_epl<KT, EPL>(kraw[buf][u], kx);
+      unpack_epl<KT, EPL>(vraw[buf][u], vx);
       float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) dot = fmaf(q[j], kx[u][j], dot);
-      for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-      if (valid[u]) update(dot, vx[u]);
+      for (int j = 0; j < EPL; ++j) dot = fmaf(q[j], kx[j], dot);
+      dot = group_dot_sum(dot, G);
+      if (s0 + u * KPW + gi < pos) update(dot, vx);
     }
+  };
+  for (int s0 = s_first; s0 < pos; s0 += 2 * stride) {   // buffers have fixed roles: no register rotation
+    if (s0 + stride < pos) issue_kv(1, s0 + stride);
+    consume(0, s0);
+    if (s0 + stride >= pos) break;
+    if (s0 + 2 * stride < pos) issue_kv(0, s0 + 2 * stride);
+    consume(1, s0 + stride);
   }
   {   // the new token itself (every block needs it; the cache copy may not be written yet by its owner block)
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) dot = fmaf(q[j], kn[j], dot);
-    for (int o = G >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    dot = group_dot_sum(dot, G);
     if (wave == 0 && gi == 0) update(dot, vn);
   }
   // merge the lane groups of this wave with shuffles (each step pairs groups `o` lanes apart), then the waves through LDS
