@@ -27,7 +27,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TR = 32;          // rows per workgroup (one MFMA tile)
 constexpr int HALO = 6;         // causal depthwise kernel 7
 
-__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu1(float v) { return vv_gelu_as(v); }   // result goes to bf16: see vv_common.h
 __device__ __forceinline__ unsigned int pack2(float a, float b) {
   const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
   return (unsigned int)(*reinterpret_cast<const bf16_t*>(&x)) | ((unsigned int)(*reinterpret_cast<const bf16_t*>(&y)) << 16);
@@ -76,6 +76,23 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   const int rows = min(TR, T - t0);
   const int cq = tid % L::F4, rloc = tid / L::F4;
   const int c0 = cq * 4;
+
+  // The weights do not depend on the activations: this wave's W1 fragments (C/32 blocks x C/16 steps x 16 B per lane, <= 128
+  // VGPRs) are requested before anything else so their L2 latency hides behind the mixer; W2 follows in double-buffered batches.
+  const int hk = (lane >> 5) * 8;                                  // k offset of this lane inside a 16-wide MFMA step
+  const int lm = lane & 31;
+  constexpr int NBW = C / 32;                                      // W1 output blocks per wave
+  constexpr int ST1 = C / 16;                                      // MFMA steps of the first GEMM
+  u32x4 w1f[NBW][ST1];
+  {
+    const bf16_t* W1 = reinterpret_cast<const bf16_t*>(B.w1);
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const bf16_t* wr = W1 + (int64_t)((wave * NBW + j) * 32 + lm) * C + hk;
+#pragma unroll
+      for (int s = 0; s < ST1; ++s) w1f[j][s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
+    }
+  }
 
   // ---- 1. window rows t0-6 .. t0+rows-1: raw values stay in registers, normalised values go to LDS -----------------------
   float4 own[L::NI];
@@ -152,68 +169,67 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   __syncthreads();
 
   // ---- 3. hidden = gelu(W1 xh + b1): 4C/32 output blocks, C/32 per wave; K = C ----------------------------------------------
-  const int hk = (lane >> 5) * 8;                                  // k offset of this lane inside a 16-wide MFMA step
-  const int lm = lane & 31;
+  // second GEMM: C/32 output blocks, K = 4C split over 4 / (C/32) waves; its first weight batch is requested here, before the
+  // first GEMM's epilogue and the barrier
+  constexpr int ST2 = (4 * C / 16) / L::KS;                        // MFMA steps of this wave in the second GEMM
+  constexpr int UB = ST2 < 8 ? ST2 : 8;
+  const int nblk = wave % L::NB2, kpart = wave / L::NB2;
+  const bf16_t* w2r = reinterpret_cast<const bf16_t*>(B.w2) + (int64_t)(nblk * 32 + lm) * (4 * C) + kpart * ST2 * 16 + hk;
+  u32x4 w2a[UB], w2b[UB];
+#pragma unroll
+  for (int i = 0; i < UB; ++i) w2a[i] = *reinterpret_cast<const u32x4*>(w2r + i * 16);
   {
-    constexpr int NBW = C / 32;                                    // blocks per wave
-    constexpr int ST = C / 16;                                     // MFMA steps
-    const bf16_t* W1 = reinterpret_cast<const bf16_t*>(B.w1);
     const bf16_t* xf = xh + lm * L::P1 + hk;
 #pragma unroll
-    for (int j0 = 0; j0 < NBW; j0 += 2) {                          // two blocks' weights (<= 16 x 16 B per lane) in flight
-      constexpr int JB = (NBW >= 2) ? 2 : 1;
-      u32x4 wa[JB][ST];
+    for (int j = 0; j < NBW; ++j) {
+      f32x16 acc;
 #pragma unroll
-      for (int j = 0; j < JB; ++j) {
-        const bf16_t* wr = W1 + (int64_t)((wave * NBW + j0 + j) * 32 + lm) * C + hk;
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < ST; ++s) wa[j][s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
+      for (int s = 0; s < ST1; ++s) {
+        const u32x4 xb = *reinterpret_cast<const u32x4*>(xf + s * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1f[j][s]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
       }
+      const int n0 = (wave * NBW + j) * 32;
 #pragma unroll
-      for (int j = 0; j < JB; ++j) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < ST; ++s) {
-          const u32x4 xb = *reinterpret_cast<const u32x4*>(xf + s * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[j][s]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
-        }
-        const int n0 = (wave * NBW + j0 + j) * 32;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                              // acc[4g + i]: channel n0 + 8g + 4(lane >> 5) + i, row lane & 31
-          const int n = n0 + 8 * g + 4 * (lane >> 5);
-          const float4 b1 = *reinterpret_cast<const float4*>(B.b1 + n);
-          uint2 p;
-          p.x = pack2(gelu1(acc[4 * g] + b1.x), gelu1(acc[4 * g + 1] + b1.y));
-          p.y = pack2(gelu1(acc[4 * g + 2] + b1.z), gelu1(acc[4 * g + 3] + b1.w));
-          *reinterpret_cast<uint2*>(hid + lm * L::P2 + n) = p;
-        }
+      for (int g = 0; g < 4; ++g) {                              // acc[4g + i]: channel n0 + 8g + 4(lane >> 5) + i, row lane & 31
+        const int n = n0 + 8 * g + 4 * (lane >> 5);
+        const float4 b1 = *reinterpret_cast<const float4*>(B.b1 + n);
+        uint2 p;
+        p.x = pack2(gelu1(acc[4 * g] + b1.x), gelu1(acc[4 * g + 1] + b1.y));
+        p.y = pack2(gelu1(acc[4 * g + 2] + b1.z), gelu1(acc[4 * g + 3] + b1.w));
+        *reinterpret_cast<uint2*>(hid + lm * L::P2 + n) = p;
       }
     }
   }
   __syncthreads();
 
-  // ---- 4. y = W2 hidden + b2; out = x1 + ffn_gamma y: C/32 output blocks, K = 4C split over 4 / (C/32) waves -----------------
+  // ---- 4. y = W2 hidden + b2; out = x1 + ffn_gamma y -----------------------------------------------------------------------------
   {
-    constexpr int ST = (4 * C / 16) / L::KS;                       // MFMA steps of this wave
-    const int nblk = wave % L::NB2, kpart = wave / L::NB2;
-    const bf16_t* W2 = reinterpret_cast<const bf16_t*>(B.w2);
-    const bf16_t* wr = W2 + (int64_t)(nblk * 32 + lm) * (4 * C) + kpart * ST * 16 + hk;
-    const bf16_t* hf = hid + lm * L::P2 + kpart * ST * 16 + hk;
+    const bf16_t* hf = hid + lm * L::P2 + kpart * ST2 * 16 + hk;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    constexpr int UB = ST < 8 ? ST : 8;
-#pragma unroll
-    for (int sb = 0; sb < ST; sb += UB) {
-      u32x4 wa[UB];
-#pragma unroll
-      for (int i = 0; i < UB; ++i) wa[i] = *reinterpret_cast<const u32x4*>(wr + (sb + i) * 16);
+    auto mma = [&](const u32x4 (&w)[UB], int sb) {
 #pragma unroll
       for (int i = 0; i < UB; ++i) {
         const u32x4 hb = *reinterpret_cast<const u32x4*>(hf + (sb + i) * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[i]), __builtin_bit_cast(bf16x8, hb), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, hb), acc, 0, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int sb = 0; sb < ST2; sb += 2 * UB) {                     // batches alternate between two register sets: no rotation
+      if (sb + UB < ST2) {
+#pragma unroll
+        for (int i = 0; i < UB; ++i) w2b[i] = *reinterpret_cast<const u32x4*>(w2r + (sb + UB + i) * 16);
+      }
+      mma(w2a, sb);
+      if (sb + UB < ST2) {
+        if (sb + 2 * UB < ST2) {
+#pragma unroll
+          for (int i = 0; i < UB; ++i) w2a[i] = *reinterpret_cast<const u32x4*>(w2r + (sb + 2 * UB + i) * 16);
+        }
+        mma(w2b, sb + UB);
       }
     }
     if (L::KS > 1) {                                               // fixed-order combine: deterministic

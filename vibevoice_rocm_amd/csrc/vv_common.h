@@ -38,6 +38,18 @@ void vv_block1d_set_fused(int on);
 int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s);
 
 #ifdef __HIPCC__
+// GELU (exact-erf form) with erf from Abramowitz & Stegun 7.1.26: |erf error| <= 1.5e-7, one v_exp + one v_rcp + 6 FMA instead
+// of libm's erff (~4x the instructions).  Used only where the result is rounded to bf16 (2^-9 relative) right away - the hidden
+// activation between the two FFN GEMMs of a conv block, where every lane evaluates dozens of them and erff was the longest
+// phase of the kernel.  fp32 outputs keep erff.
+__device__ __forceinline__ float vv_gelu_as(float v) {
+  const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = 1.0f - poly * __expf(-ax * ax);
+  return 0.5f * v * (1.0f + copysignf(erf_abs, x));
+}
+
 // Wave-wide (64 lanes) sum, result in every lane.  DPP row operations reduce each 16-lane row at VALU speed (4 dependent
 // v_add with a DPP operand), the four row sums are combined through readlane.  The usual __shfl_xor butterfly is six
 // dependent ds_bpermute round trips (~100+ cycles each): with one or two waves per SIMD, as in the weight-streaming

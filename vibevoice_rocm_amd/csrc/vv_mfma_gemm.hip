@@ -72,8 +72,13 @@ __device__ __forceinline__ void epi4(const vv_lin_args& a, bool vec_ok, int m, i
   float v[4] = {vin[0], vin[1], vin[2], vin[3]};
   if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
   if (a.act == VV_ACT_GELU) {
+    if (a.flags & VV_LIN_OUT_BF16) {             // rounded to bf16 below: the 1.5e-7 erf approximation is exact at that precision
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = gelu1(v[i]);
+      for (int i = 0; i < 4; ++i) v[i] = vv_gelu_as(v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gelu1(v[i]);
+    }
   } else if (a.act == VV_ACT_SWIGLU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = silu1(v[i]) * v2[i];
