@@ -5,7 +5,8 @@ acc = collections.defaultdict(lambda: [0, 0.0])
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         if r.get("Counter_Name") != "FETCH_SIZE": continue
-        name = r["Kernel_Name"].split("(")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        name = name.split("(")[0].replace("void ", "")          # keeps the template arguments, drops the parameter list
         key = f'{name} grid={r.get("Grid_Size", r.get("Grid_Size_X", ""))} wg={r.get("Workgroup_Size", r.get("Workgroup_Size_X", ""))}'
         a = acc[key]; a[0] += 1; a[1] += float(r["Counter_Value"])
 out = {k: {"launches": v[0], "fetch_size_kb_avg": v[1] / v[0], "bytes_per_launch": 2.0 * 1024.0 * v[1] / v[0]} for k, v in acc.items() if v[0] >= 4}
