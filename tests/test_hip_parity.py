@@ -393,6 +393,29 @@ def mid():
     return cfg, sd
 
 
+def test_speculative_frame_launch_is_exact(mid):
+    """generate() with the diffusion tail launched speculatively behind every LLM step (and rolled back when the token is not
+    speech_diffusion: speech_end, a speech_start straight after a frame, EOS) must reproduce the non-speculative run bit for bit."""
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfg, sd = mid
+    V = cfg.vocab
+    ST, E, D, EOS = V - 4, V - 3, V - 2, V - 1
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, V - 8, (24,), generator=g)
+    forced = [ST, D, D, ST, D, D, D, E, ST, D, E, ST, D, D, EOS]
+    noise = torch.randn(16, cfg.latent, generator=g)
+    m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
+    m.set_ddpm_inference_steps(10)
+    outs = []
+    for spec in (False, True, True):
+        m.speculative_frames = spec
+        out = m.generate(input_ids=ids[None], tokenizer=_Tok(ST, E, D, EOS), cfg_scale=1.5, forced_tokens=forced, noise=noise)
+        outs.append((out.sequences[0].tolist(), out.speech_outputs[0][0].cpu().numpy()))
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert outs[0][1].shape == (8 * cfg.hop,)
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[1][1], outs[2][1])
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 2e-2)])
 def test_generate_mid_vs_oracle(mid, dtype, tol):
     from oracle import vv_oracle as O

@@ -61,7 +61,11 @@ class Engine:
         self.token_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.logits_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.forced_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()
-        self.noise_host = torch.zeros(cfg.latent, dtype=torch.float32).pin_memory()
+        self.noise_host = torch.zeros(2, cfg.latent, dtype=torch.float32).pin_memory()   # double-buffered: the host runs a frame ahead
+        self._noise_k = 0
+        self._tok_event = torch.cuda.Event()
+        with torch.cuda.stream(self.stream):
+            self._state_snap = torch.empty_like(self.w.state_blob())
         self.scheduler = DPMSolverMultistepScheduler(num_train_timesteps=cfg.ddpm_steps, beta_schedule=cfg.beta_schedule,
                                                      prediction_type=cfg.prediction_type)
         self.n_steps = 0
@@ -238,6 +242,9 @@ class Engine:
     def _seq_B(self, cfg_scale):
         """speech_diffusion tail: sample latent, decode audio, re-encode semantics, build the next embedding."""
         lib, w, cfg = self.lib, self.w, self.cfg
+        # snapshot of the streaming state (one ~1.4 MB copy): lets a frame that was launched speculatively be rolled back
+        blob = w.state_blob()
+        self._ck(lib.vv_copy_rows(blob.data_ptr(), blob.numel(), self._state_snap.data_ptr(), blob.numel(), 1, blob.numel(), self.sp), "snapshot")
         self._ck(lib.vv_head_sample(C.byref(w.head), self.hidden2.data_ptr(), cfg.hidden, self.noise_dev.data_ptr(),
                                     self.temb.data_ptr(), self._coefs, self.n_steps, cfg_scale, self.latent.data_ptr(),
                                     self._head_ws.data_ptr(), self.sp), "vv_head_sample")
@@ -323,10 +330,37 @@ class Engine:
 
     def step_speech(self, noise: torch.Tensor):
         """Phase B.  `noise` is the CPU fp32 [latent] row the reference would have drawn (modeling_vibevoice_inference.py:699)."""
-        self.noise_host.copy_(noise.reshape(-1)[: self.cfg.latent])
+        self._noise_k ^= 1
+        nh = self.noise_host[self._noise_k]
+        nh.copy_(noise.reshape(-1)[: self.cfg.latent])
         with torch.cuda.stream(self.stream):
-            self.noise_dev.copy_(self.noise_host, non_blocking=True)
+            self.noise_dev.copy_(nh, non_blocking=True)
             self._run("B", self._seq_B, float(self.cfg_scale))
+
+    def step_decode_speculative(self, tok_start: int, tok_diff: int, forced: Optional[int], noise: torch.Tensor) -> int:
+        """Phase A, then phase B enqueued right behind it ON THE ASSUMPTION that the token is speech_diffusion (the steady state
+        of a dialogue), then one host wait on the token alone.  The GPU therefore never idles between A and B while the host
+        wakes up and decides; if the token turns out to be something else the caller rolls the speech state back
+        (`rollback_speech_state`) - phase B touches nothing else that survives (x2 is rewritten by the embed phase)."""
+        self._noise_k ^= 1
+        nh = self.noise_host[self._noise_k]
+        nh.copy_(noise.reshape(-1)[: self.cfg.latent])
+        with torch.cuda.stream(self.stream):
+            self.forced_host[0] = -1 if forced is None else int(forced)
+            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._run("A", self._seq_A, int(tok_start), int(tok_diff))
+            self.token_host.copy_(self.token_dev, non_blocking=True)
+            self._tok_event.record(self.stream)
+            self.noise_dev.copy_(nh, non_blocking=True)
+            self._run("B", self._seq_B, float(self.cfg_scale))
+        self._tok_event.synchronize()
+        return int(self.token_host[0])
+
+    def rollback_speech_state(self):
+        """Undo the streaming-state updates of the last phase B (a mis-speculated frame)."""
+        blob = self.w.state_blob()
+        with torch.cuda.stream(self.stream):
+            self._ck(self.lib.vv_copy_rows(self._state_snap.data_ptr(), blob.numel(), blob.data_ptr(), blob.numel(), 1, blob.numel(), self.sp), "rollback")
 
     def step_embed(self):
         with torch.cuda.stream(self.stream):

@@ -85,6 +85,9 @@ class VibeVoiceForConditionalGenerationInference:
             raise KeyError(f"state dict is missing {len(missing)} tensors, e.g. {missing[:4]}")
         self.config = config
         self.dtype = torch_dtype
+        # launch a frame's diffusion tail right behind the LLM step while the host still waits for the token (rolled back when the
+        # token is not speech_diffusion); results are identical either way (tests/test_hip_parity.py)
+        self.speculative_frames = True
         self.engine = Engine(config, state_dict, device=device, dtype=torch_dtype, use_graphs=use_graphs)
         self.device = self.engine.device
         self.ddpm_inference_steps = config.ddpm_infer
@@ -259,6 +262,9 @@ class VibeVoiceForConditionalGenerationInference:
         reach_max = False
         frame = 0
         stream_idx = torch.tensor([sample_idx])
+        # speculative frame launch needs the greedy / forced token path (a sampled token needs the logits on the host first)
+        speculate = self.speculative_frames and sample_fn is None and eng.use_graphs
+        prev_tok, pending_nz = None, None
         for step in range(max_steps):
             if stop_check_fn is not None and stop_check_fn():                                  # :432-438
                 if verbose:
@@ -272,14 +278,26 @@ class VibeVoiceForConditionalGenerationInference:
                 reach_max = True
                 break
             forced = forced_tokens[step] if (forced_tokens is not None and step < len(forced_tokens)) else None
+            speculated = False
             if step == 0:
                 eng.prefill(x0, row=0, pos0=0)
                 tok = eng.first_token(ST, SD, forced, sample_fn)
                 if tok == SD:
                     # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
                     eng.prefill(eng.embed_ids(torch.tensor([ST])), row=1, pos0=0)
+            elif speculate and prev_tok == SD and (noise is None or pending_nz is not None or frame < len(noise)):
+                # steady state of a dialogue: the frame's diffusion tail is enqueued right behind the LLM step, the host waits
+                # for the token only.  The noise row is the draw the reference makes when the token IS speech_diffusion; a draw
+                # made for a mis-speculated frame is kept for the next real one (same RNG sequence).
+                if pending_nz is None:
+                    pending_nz = noise[frame] if noise is not None else torch.randn(2, cfg.latent)[0]   # the reference's CPU draw (:699)
+                tok = eng.step_decode_speculative(ST, SD, forced, pending_nz)
+                speculated = True
+                if tok != SD:
+                    eng.rollback_speech_state()
             else:
                 tok = eng.step_decode(ST, SD, forced, sample_fn)                                # :478-496 (+ speculative :581-583)
+            prev_tok = tok
             seq.append(tok)
             if tok == EOS:                                                                      # :517-526
                 if verbose:
@@ -291,11 +309,11 @@ class VibeVoiceForConditionalGenerationInference:
                 with torch.cuda.stream(eng.stream):
                     eng.reset_speech_caches()
             if tok == SD:                                                                       # :571-670
-                if noise is not None:
-                    nz = noise[frame]
-                else:
-                    nz = torch.randn(2, cfg.latent)[0]                                          # the reference's CPU draw (:699)
-                eng.step_speech(nz)
+                if not speculated:
+                    if pending_nz is None:
+                        pending_nz = noise[frame] if noise is not None else torch.randn(2, cfg.latent)[0]   # the reference's CPU draw (:699)
+                    eng.step_speech(pending_nz)
+                pending_nz = None
                 with torch.cuda.stream(eng.stream):
                     chunk = eng.wav.clone()
                 chunks.append(chunk)

@@ -38,6 +38,10 @@ class DeviceWeights:
         self._keep: List[object] = []     # tensors / ctypes arrays that must outlive the descriptors
         self._sd = sd
         self.state_tensors: Dict[str, List[torch.Tensor]] = {"acoustic_dec": [], "semantic_enc": []}
+        # every streaming-state tensor (conv left contexts, mixer histories) is a 256-byte aligned view into ONE arena, so the
+        # engine can snapshot / roll back the whole speech state with a single copy (speculative frame launch)
+        self._state_arena = torch.zeros(1 << 21, dtype=torch.float32, device=self.device)
+        self._state_used = 0
         self._build_llm()
         self._build_head()
         self.dec = self._build_convnet("model.acoustic_tokenizer.decoder.", decoder=True, filters=cfg.ac_dec_filters,
@@ -70,6 +74,18 @@ class DeviceWeights:
         t = self._aligned(t.detach().to(device=self.device, dtype=torch.float32).contiguous())
         self._keep.append(t)
         return t
+
+    def _state_zeros(self, rows: int, ch: int) -> torch.Tensor:
+        n = rows * ch
+        if self._state_used + n > self._state_arena.numel():
+            raise ValueError("streaming-state arena too small for this tokenizer configuration")
+        t = self._state_arena[self._state_used: self._state_used + n].view(rows, ch)
+        self._state_used += (n + 63) // 64 * 64
+        return t
+
+    def state_blob(self) -> torch.Tensor:
+        """All streaming state of the speech path as one flat fp32 tensor."""
+        return self._state_arena[: max(self._state_used, 64)]
 
     def _zeros(self, *shape) -> torch.Tensor:
         t = torch.zeros(*shape, dtype=torch.float32, device=self.device)
@@ -157,7 +173,7 @@ class DeviceWeights:
         c.w, c.b = L.ptr(self._mat(wl)), L.ptr(self._vec(bl))
         c.cin, c.cout, c.kk, c.stride, c.transposed = cin, cout, k, stride, int(transposed)
         if state_key is not None and ctx > 0:
-            st = self._zeros(ctx, cin)
+            st = self._state_zeros(ctx, cin)
             self.state_tensors[state_key].append(st)
             c.state = L.ptr(st)
         else:
@@ -179,7 +195,7 @@ class DeviceWeights:
             b.w1, b.b1 = L.ptr(self._mat(sd[q + "ffn.linear1.weight"])), L.ptr(self._vec(sd[q + "ffn.linear1.bias"]))
             b.w2, b.b2 = L.ptr(self._mat(sd[q + "ffn.linear2.weight"])), L.ptr(self._vec(sd[q + "ffn.linear2.bias"]))
             if state_key is not None:
-                h = self._zeros(6, ch)
+                h = self._state_zeros(6, ch)
                 self.state_tensors[state_key].append(h)
                 b.hist = L.ptr(h)
             else:
