@@ -222,6 +222,34 @@ def test_block1d_single_launch_vs_torch(lib, C_, T):
     assert l.vv_block1d(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), 8, C_, eps, None) != 0
 
 
+@pytest.mark.parametrize("m,n,k,dual", [(330, 2048, 1536, False), (200, 8960, 1536, True), (129, 1536, 8960, False), (128, 128, 32, False), (513, 256, 96, True)])
+def test_prefill_gemm_bf16_activations(lib, m, n, k, dual):
+    """vv_linear with VV_LIN_X_BF16 at prompt sizes (the direct-stream matrix-core GEMM of the prefill, 128-row strips): bias /
+    SwiGLU / residual epilogues against torch on the same bf16 operands."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g)).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    w2 = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    bias, res = torch.randn(n, generator=g) * 0.1, torch.randn(m, n, generator=g)
+    xd, wd, w2d, bd, rd = x.cuda(), w.cuda(), w2.cuda(), bias.cuda(), res.cuda()
+    out = torch.full((m, n), float("nan"), device="cuda")
+    a = L.LinArgs()
+    a.x, a.ldx, a.m, a.n, a.k, a.wdt, a.out, a.ldo = xd.data_ptr(), k, m, n, k, L.VV_BF16, out.data_ptr(), n
+    a.w = wd.data_ptr()
+    a.flags = L.LIN_X_BF16
+    if dual:
+        a.w2, a.act = w2d.data_ptr(), 2
+        want = torch.nn.functional.silu(x.float() @ w.float().T) * (x.float() @ w2.float().T)
+    else:
+        a.bias, a.res, a.ldres = bd.data_ptr(), rd.data_ptr(), n
+        want = x.float() @ w.float().T + bias + res
+    L.check(l.vv_linear(C.byref(a), None), "vv_linear")
+    torch.cuda.synchronize()
+    assert rel_rms(out.cpu().numpy(), want.numpy()) < 2e-5
+
+
 def test_linear_rejects_bad_args(lib):
     L = lib
     l = L.load()
