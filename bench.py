@@ -186,6 +186,25 @@ def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
                      "not the headline metric, which is one dialogue per GPU")
 
 
+def fp8_leg(cfg, sd, device, args, wl):
+    """Extra (NOT the headline value, which is bf16): the same workload with weight-only fp8 (e4m3fn codes + power-of-two row scales)
+    on the per-frame weight-streaming GEMVs - LLM linears, head SwiGLU matrices, the 1-row conv stage."""
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    m8 = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=torch.bfloat16, use_graphs=not args.no_graphs,
+                                                    weight_quant="fp8")
+    m8.set_ddpm_inference_steps(args.ddpm_steps)
+    n = 0
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = run_generate(m8, wl, args.cfg_scale).speech_outputs[0].shape[-1]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dict(value=round(n / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3), weights="e4m3fn + power-of-two row scales",
+                note="same workload, weight-only fp8 on the decode GEMVs (bf16 activations, fp32 accumulate); an optional mode "
+                     "(weight_quant='fp8'), not the headline metric")
+
+
 def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
     """The CPU oracle on a bounded sample of the same workload (kind: port)."""
     from oracle import vv_oracle as O
@@ -237,6 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-fp8-leg", dest="fp8_leg", action="store_false", help="skip the extra weight-only-fp8 leg")
     ap.add_argument("--concurrent", type=int, default=3, help="extra leg: N independent dialogues concurrently on one GPU (0/1 = skip)")
     args = ap.parse_args()
 
@@ -274,7 +294,7 @@ def main():
     model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
     log(f"engine ready ({model.engine.w.nbytes() / 1e9:.2f} GB resident)")
     model._bench_sd = sd if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    model._bench_sd_all = sd if (rank == 0 and world == 1 and args.concurrent > 1) else None
+    model._bench_sd_all = sd if (rank == 0 and world == 1 and (args.concurrent > 1 or args.fp8_leg)) else None
     if model._bench_sd is None and model._bench_sd_all is None:
         del sd
     model.set_ddpm_inference_steps(args.ddpm_steps)
@@ -356,6 +376,9 @@ def main():
     if rank == 0 and single and args.concurrent > 1:
         result["concurrent_streams"] = concurrent_leg(model, cfg, model._bench_sd_all, dtype, device, args, args.concurrent)
         log(f"concurrent x{args.concurrent}: {result['concurrent_streams']['value']} audio-sec/s aggregate")
+    if rank == 0 and single and args.fp8_leg and dtype == torch.bfloat16 and model._bench_sd_all is not None:
+        result["fp8_weights"] = fp8_leg(cfg, model._bench_sd_all, device, args, wl)
+        log(f"fp8 weights: {result['fp8_weights']['value']} audio-sec/s")
     if rank == 0 and single and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline_leg(model, cfg, args.cfg_scale, args.ddpm_steps)
         log("cpu baseline done")

@@ -28,7 +28,7 @@ extern "C" {
 
 typedef void* vv_stream_t; /* hipStream_t */
 
-enum { VV_F32 = 0, VV_BF16 = 1 };
+enum { VV_F32 = 0, VV_BF16 = 1, VV_FP8 = 2 /* e4m3fn bytes + per-output-row fp32 scale (vv_lin_args.wscale); streaming GEMV (m <= 2) only */ };
 enum { VV_OK = 0, VV_E_ARG = -1, VV_E_HIP = -2, VV_E_UNSUPPORTED = -3 };
 enum { VV_PRO_NONE = 0, VV_PRO_RMSNORM = 1, VV_PRO_SILU = 2 };
 enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
@@ -80,6 +80,8 @@ typedef struct vv_lin_args {
   float* out;
   int64_t ldo;
   int flags;   /* VV_LIN_* */
+  const float* wscale;   /* wdt == VV_FP8: out = (W8 x) * wscale[n] (+ bias ...); else ignored */
+  const float* w2scale;
 } vv_lin_args;
 
 int vv_linear(const vv_lin_args* a, vv_stream_t stream);
@@ -150,6 +152,10 @@ int vv_advance_lens(int* lens, const int* token, int tok_start, int tok_diffusio
 /* ------------------------------------------------------------------------------------------------------------
  * Composite operators (one call enqueues the whole launch sequence of a component).
  * ------------------------------------------------------------------------------------------------------------ */
+/* Optional weight-only fp8 companion of a matrix for the batch-1/2 decode GEMVs: e4m3fn bytes [N, K] and one
+ * fp32 scale per output row.  q == NULL: not quantised.  The bf16 matrix stays the operand of every GEMM-shaped use (prefill, T > 2). */
+typedef struct vv_w8 { const void* q; const float* scale; } vv_w8;
+
 typedef struct vv_llm_layer {
   const float* ln1;  /* input_layernorm.weight */
   const float* ln2;  /* post_attention_layernorm.weight */
@@ -159,6 +165,7 @@ typedef struct vv_llm_layer {
   const void* wgate; /* [inter, hidden] */
   const void* wup;
   const void* wdown; /* [hidden, inter] */
+  vv_w8 q_qkv, q_o, q_gate, q_up, q_down;
 } vv_llm_layer;
 
 typedef struct vv_llm {
@@ -182,6 +189,7 @@ typedef struct vv_head_layer {
   const void* wup;
   const void* wdown;  /* [D, ffn] */
   const void* adaln;  /* [3D, D]: shift | scale | gate */
+  vv_w8 q_gate, q_up, q_down;
 } vv_head_layer;
 
 #define VV_HEAD_CHAIN 1 /* vv_head.flags: run the solver loop as ONE persistent chained kernel (vv_chain.hip; experimental, needs the GPU to itself) instead of one launch per GEMV */
@@ -226,6 +234,7 @@ typedef struct vv_block {
   const void* w1; const float* b1;  /* [4C, C] */
   const void* w2; const float* b2;  /* [C, 4C] */
   float* hist;                      /* [6, C] streaming state or NULL */
+  vv_w8 q_w1, q_w2;                 /* used when the block runs as GEMVs (T <= 2 rows: stage 0 of a streaming frame) */
 } vv_block;
 
 /* One whole Block1D (mixer + FFN, vibevoice/modular/modular_vibevoice_tokenizer.py:555-600) as a single launch: x[T, C] -> out[T, C]

@@ -250,6 +250,77 @@ def test_prefill_gemm_bf16_activations(lib, m, n, k, dual):
     assert rel_rms(out.cpu().numpy(), want.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("m,n,k,dual", [(2, 4608, 1536, True), (2, 1536, 4608, False), (1, 2048, 8192, False), (2, 2048, 1536, False),
+                                        (2, 1536, 8960, False), (2, 96, 512, False), (2, 3584, 10752, True), (1, 257, 24, False), (2, 64, 18944, False)])
+def test_linear_fp8_weights(lib, m, n, k, dual):
+    """Weight-only fp8 (e4m3fn codes + power-of-two row scales) on the streaming GEMV: bit pattern decode, scale, RMSNorm prologue,
+    bias / SwiGLU / residual epilogues against torch on the dequantised matrix."""
+    from vibevoice_rocm_amd.weights import quantize_e4m3_pow2
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(7 * m + n + k)
+    x = torch.randn(m, k, generator=g)
+    w, w2 = torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, k, generator=g) / k ** 0.5
+    w[0, :8] = torch.tensor([448.0, -448.0, 2 ** -9, -2 ** -9, 0.0, 1.0, -1.75, 240.0]) * w.abs().max() / 448.0   # range ends, subnormal
+    q1, s1, e1 = quantize_e4m3_pow2(w)
+    q2, s2, e2 = quantize_e4m3_pow2(w2)
+    assert torch.equal(e1.bfloat16().float(), e1), "dequantised weights must be exact in bf16"
+    nw, bias, res = 1 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(n, generator=g), torch.randn(m, n, generator=g)
+    d = [t.cuda() for t in (x, q1, s1, q2, s2, nw, bias, res)]
+    out = torch.full((m, n), float("nan"), device="cuda")
+    a = L.LinArgs()
+    a.x, a.ldx, a.m, a.n, a.k, a.wdt, a.out, a.ldo = d[0].data_ptr(), k, m, n, k, L.VV_FP8, out.data_ptr(), n
+    a.w, a.wscale = d[1].data_ptr(), d[2].data_ptr()
+    xn = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * nw
+    if dual:
+        a.w2, a.w2scale, a.act = d[3].data_ptr(), d[4].data_ptr(), 2
+        a.pro, a.norm_w, a.eps = 1, d[5].data_ptr(), 1e-6
+        want = torch.nn.functional.silu(xn @ e1.T) * (xn @ e2.T)
+    else:
+        a.bias, a.res, a.ldres = d[6].data_ptr(), d[7].data_ptr(), n
+        want = x @ e1.T + bias + res
+    L.check(l.vv_linear(C.byref(a), None), "vv_linear fp8")
+    torch.cuda.synchronize()
+    assert rel_rms(out.cpu().numpy(), want.numpy()) < 2e-6
+    a.m = 12                                                   # GEMM-shaped: the bf16 matrix is the operand there, fp8 is refused
+    assert l.vv_linear(C.byref(a), None) != 0
+
+
+def test_generate_mid_fp8_weights_vs_oracle(mid):
+    """weight_quant="fp8": generate() against the oracle run on the effective (dequantised) matrices - prefill (bf16 copies) and
+    decode (fp8 codes) must be the same model."""
+    from oracle import vv_oracle as O
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    from vibevoice_rocm_amd.weights import fp8_effective_state_dict, fp8_matrix_names
+    cfg, sd = mid
+    eff = fp8_effective_state_dict(cfg, sd)
+    names = set(fp8_matrix_names(cfg))
+    sd_o = {k: (eff[k] if k in names else (v.to(torch.bfloat16).float() if v.dim() >= 2 else v)) for k, v in sd.items()}
+    V = cfg.vocab
+    ST, E, D, EOS = V - 4, V - 3, V - 2, V - 1
+    special = dict(speech_start=ST, speech_end=E, speech_diffusion=D, eos=EOS)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, V - 8, (70,), generator=g)            # >= 64 rows: the prompt takes the prefill (bf16 GEMM) path
+    forced = [ST] + [D] * 5 + [E, EOS]
+    noise = torch.randn(5, cfg.latent, generator=g)
+    ref = O.generate(sd_o, cfg.as_dict(), ids.tolist(), torch.zeros(70, dtype=torch.bool), None, special, noise, cfg_scale=2.0, n_steps=10,
+                     forced_tokens=forced)
+    m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16, weight_quant="fp8")
+    m.engine.bf16_t_quirk = False
+    m.set_ddpm_inference_steps(10)
+    out = m.generate(input_ids=ids[None], tokenizer=_Tok(ST, E, D, EOS), cfg_scale=2.0, forced_tokens=forced, noise=noise)
+    assert out.sequences[0, 70:].tolist() == forced
+    got, want = out.speech_outputs[0][0].cpu().numpy(), torch.cat(ref.audio).numpy()
+    assert got.shape == want.shape == (5 * cfg.hop,)
+    assert rel_rms(got, want) < 2e-2
+    # and it is a different model from the unquantised one (the test would be vacuous otherwise)
+    m2 = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
+    m2.engine.bf16_t_quirk = False
+    m2.set_ddpm_inference_steps(10)
+    out2 = m2.generate(input_ids=ids[None], tokenizer=_Tok(ST, E, D, EOS), cfg_scale=2.0, forced_tokens=forced, noise=noise)
+    assert rel_rms(out2.speech_outputs[0][0].cpu().numpy(), got) > 5e-2
+
+
 def test_linear_rejects_bad_args(lib):
     L = lib
     l = L.load()

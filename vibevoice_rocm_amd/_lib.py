@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvv_hip.so")
 
-VV_F32, VV_BF16 = 0, 1
+VV_F32, VV_BF16, VV_FP8 = 0, 1, 2
 PRO_NONE, PRO_RMSNORM, PRO_SILU = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
 LIN_X_BF16, LIN_OUT_BF16, LIN_W_REUSED = 1, 2, 4
@@ -23,11 +23,15 @@ vp = C.c_void_p
 i64 = C.c_int64
 
 
+class W8(C.Structure):      # vv_w8: optional fp8 (e4m3fn) companion of a matrix + per-output-row scale
+    _fields_ = [("q", vp), ("scale", vp)]
+
+
 class LinArgs(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("m", C.c_int), ("pro", C.c_int), ("norm_w", vp), ("eps", C.c_float),
                 ("mod_shift", vp), ("mod_scale", vp), ("ld_mod", i64), ("w", vp), ("w2", vp), ("bias", vp),
                 ("n", C.c_int), ("k", C.c_int), ("wdt", C.c_int), ("act", C.c_int), ("gate", vp), ("gate_ld", i64),
-                ("res", vp), ("ldres", i64), ("out", vp), ("ldo", i64), ("flags", C.c_int)]
+                ("res", vp), ("ldres", i64), ("out", vp), ("ldo", i64), ("flags", C.c_int), ("wscale", vp), ("w2scale", vp)]
 
 
 class KV(C.Structure):
@@ -36,7 +40,8 @@ class KV(C.Structure):
 
 
 class LlmLayer(C.Structure):
-    _fields_ = [("ln1", vp), ("ln2", vp), ("wqkv", vp), ("bqkv", vp), ("wo", vp), ("wgate", vp), ("wup", vp), ("wdown", vp)]
+    _fields_ = [("ln1", vp), ("ln2", vp), ("wqkv", vp), ("bqkv", vp), ("wo", vp), ("wgate", vp), ("wup", vp), ("wdown", vp),
+                ("q_qkv", W8), ("q_o", W8), ("q_gate", W8), ("q_up", W8), ("q_down", W8)]
 
 
 class Llm(C.Structure):
@@ -46,7 +51,7 @@ class Llm(C.Structure):
 
 
 class HeadLayer(C.Structure):
-    _fields_ = [("norm_w", vp), ("wgate", vp), ("wup", vp), ("wdown", vp), ("adaln", vp)]
+    _fields_ = [("norm_w", vp), ("wgate", vp), ("wup", vp), ("wdown", vp), ("adaln", vp), ("q_gate", W8), ("q_up", W8), ("q_down", W8)]
 
 
 class Head(C.Structure):
@@ -62,7 +67,7 @@ class DpmCoef(C.Structure):
 
 class Block(C.Structure):
     _fields_ = [("gamma", vp), ("ffn_gamma", vp), ("norm_w", vp), ("ffn_norm_w", vp), ("dw_w", vp), ("dw_b", vp),
-                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("hist", vp)]
+                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("hist", vp), ("q_w1", W8), ("q_w2", W8)]
 
 
 class Conv(C.Structure):

@@ -30,6 +30,15 @@ __device__ __forceinline__ void unpack8(const u32x4 v, float (&o)[8]) {
   o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+// 8 e4m3fn weights in the low 8 bytes of the tile register (fp8 weight-only mode: 8-byte loads per lane)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void unpack8_f8(const u32x4 v, float (&o)[8]) {
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
+}
+
 __device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v, float v2) {
   if (a.bias) v += a.bias[n];
   if (a.act == VV_ACT_GELU) v = gelu1(v);
@@ -42,16 +51,19 @@ __device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v,
 // epilogue operands (bias / adaLN gate / residual) of one output: their addresses are known before the dot product is, so
 // they are loaded one row group ahead, in front of the weight loads that follow them in the queue (loads return in order: an
 // operand load issued at epilogue time would sit behind two row groups of prefetched weights)
-struct EpiOp { float b, g, r; };
+struct EpiOp { float b, g, r, s, s2; };   // bias, gate, residual, fp8 row scales
 __device__ __forceinline__ EpiOp epi_load(const vv_lin_args& a, int m, int n) {
   EpiOp e;
   e.b = a.bias ? a.bias[n] : 0.f;
   e.g = a.gate ? (a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n]) : 1.f;
   e.r = a.res ? a.res[(int64_t)m * a.ldres + n] : 0.f;
+  e.s = (a.wdt == VV_FP8) ? a.wscale[n] : 1.f;
+  e.s2 = (a.wdt == VV_FP8 && a.w2) ? a.w2scale[n] : 1.f;
   return e;
 }
 __device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, float v, float v2, const EpiOp& e) {
-  v += e.b;
+  v = v * e.s + e.b;                             // e.s = 1 unless the weights are fp8 codes with a row scale
+  v2 *= e.s2;
   if (a.act == VV_ACT_GELU) v = gelu1(v);
   else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
   if (a.gate) v *= e.g;
@@ -61,7 +73,7 @@ __device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, floa
 
 int g_blocks_override = 0;   // tuning hook (vv_tune)
 
-template <int M, bool DUAL, int KSPLIT, int KU, int RW>
+template <int M, bool DUAL, int KSPLIT, int KU, int RW, bool F8>
 __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
   constexpr int NW = (KSPLIT == 1) ? 4 : KSPLIT;     // waves per block
   __shared__ float red[NW * M];
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
     if (!kval[u]) koff[u] = 0;                    // any valid address; the activation there is forced to 0
   }
   const bool reused = (a.flags & VV_LIN_W_REUSED) != 0;
+  constexpr bool f8 = F8;                        // weight-only fp8 is its own instantiation: the bf16 kernels carry none of it
   // the first row group's weight loads are issued before the activation prologue so both latencies overlap
   const int gstride = (KSPLIT == 1) ? gridDim.x * 4 : gridDim.x;
   int g = (KSPLIT == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
@@ -93,6 +106,15 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
       const int n = min(grp * RW + r, N - 1);
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
+        if (f8) {                // e4m3fn bytes: this lane's 8 weights are 8 bytes
+          const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(a.w) + (int64_t)n * K + koff[u]));
+          b[r][u].x = t.x; b[r][u].y = t.y;
+          if (DUAL) {
+            const u32x2 t2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(a.w2) + (int64_t)n * K + koff[u]));
+            b2[r][u].x = t2.x; b2[r][u].y = t2.y;
+          }
+          continue;
+        }
         const u32x4* p1 = reinterpret_cast<const u32x4*>(W + (int64_t)n * K + koff[u]);
         const u32x4* p2 = reinterpret_cast<const u32x4*>(W2 + (int64_t)n * K + koff[u]);
         if (reused) {            // weights re-read by the next solver step: leave them in L2 / Infinity Cache
@@ -109,7 +131,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
   // group; K split: thread of the block), so activations like GELU run once per output in parallel lanes instead of RW x M
   // times in lane 0, and each owner fetches its own operands one group ahead
   constexpr int NE = 1;
-  const bool has_eo = a.bias || a.gate || a.res;
+  const bool has_eo = a.bias || a.gate || a.res || a.wdt == VV_FP8;
   const int eid = (KSPLIT == 1) ? lane : tid;
   EpiOp eo_cur[NE], eo_nxt[NE];
   auto load_eo = [&](EpiOp (&e)[NE], int grp) {
@@ -120,7 +142,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
     }
   };
 #pragma unroll
-  for (int i = 0; i < NE; ++i) { eo_cur[i].b = 0.f; eo_cur[i].g = 1.f; eo_cur[i].r = 0.f; eo_nxt[i] = eo_cur[i]; }
+  for (int i = 0; i < NE; ++i) { eo_cur[i].b = 0.f; eo_cur[i].g = 1.f; eo_cur[i].r = 0.f; eo_cur[i].s = 1.f; eo_cur[i].s2 = 1.f; eo_nxt[i] = eo_cur[i]; }
   if (g < n_groups) { load_eo(eo_cur, g); issue(cur, cur2, g); }
   if (g + gstride < n_groups) { load_eo(eo_nxt, g + gstride); issue(nxt, nxt2, g + gstride); }   // two row groups in flight before the prologue even starts
   float xr[M][KU][8];
@@ -197,8 +219,8 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         float w[8], w2[8];
-        unpack8(cur[r][u], w);
-        if (DUAL) unpack8(cur2[r][u], w2);
+        if (f8) { unpack8_f8(cur[r][u], w); if (DUAL) unpack8_f8(cur2[r][u], w2); }
+        else { unpack8(cur[r][u], w); if (DUAL) unpack8(cur2[r][u], w2); }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
 #pragma unroll
@@ -273,7 +295,13 @@ void launch_rw(const vv_lin_args& a, hipStream_t s) {
   const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : (a.k > 6144 ? 512 : 1024);
   int blocks = work < cap ? work : cap;
   if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
-  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
+  if constexpr (M <= 2) {                        // fp8 weights: decode rows only
+    if (a.wdt == VV_FP8) {
+      hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW, true>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW, false>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
 }
 
 int g_small_rw = 2;           // rows per wave step for narrow non-dual matrices (tuning hook)
@@ -330,9 +358,10 @@ void vv_gemv_stream_set_small_rw(int r) { g_small_rw = r; }
 
 // returns 1 when the call was launched here, 0 when the shape/alignment is not covered (caller falls back)
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {
-  if (a.wdt != VV_BF16 || a.m > 8 || a.k % 8) return 0;
+  if ((a.wdt != VV_BF16 && a.wdt != VV_FP8) || a.m > 8 || a.k % 8) return 0;
+  if (a.wdt == VV_FP8 && (a.m > 2 || !a.wscale || (a.w2 && !a.w2scale) || (uintptr_t)a.w % 8 || (a.w2 && (uintptr_t)a.w2 % 8))) return 0;
   if (a.m > 4) {
-    if (a.w2) return 0;
+    if (a.w2 || a.wdt != VV_BF16) return 0;
     if ((uintptr_t)a.w % 16 || (uintptr_t)a.x % 16 || a.ldx % 4) return 0;
     if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
     if (a.mod_scale && ((uintptr_t)a.mod_scale % 16 || (uintptr_t)a.mod_shift % 16 || a.ld_mod % 4)) return 0;
@@ -345,7 +374,8 @@ int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {
     if (ks > 1) ku8 = 2;
     return launch_m8(a, s, ks, ku8) ? 1 : 0;
   }
-  if ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16) || (uintptr_t)a.x % 16) return 0;
+  if (a.wdt == VV_BF16 && ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16))) return 0;
+  if ((uintptr_t)a.x % 16) return 0;
   if (a.m > 1 && a.ldx % 4) return 0;
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if (a.mod_scale && ((uintptr_t)a.mod_scale % 16 || (uintptr_t)a.mod_shift % 16 || a.ld_mod % 4)) return 0;

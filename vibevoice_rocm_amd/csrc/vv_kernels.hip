@@ -585,6 +585,10 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   }
   if (a->wdt == VV_F32) rc = launch_linear<float>(*a, s);
   else if (a->wdt == VV_BF16) rc = launch_linear<bf16_t>(*a, s);
+  else if (a->wdt == VV_FP8) {
+    // weight-only fp8 exists for the weight-streaming GEMV alone (<= 2 rows); GEMM-shaped calls use the bf16 matrix
+    rc = vv_launch_gemv_stream(*a, s) ? 0 : vv_set_error(VV_E_UNSUPPORTED, "vv_linear: fp8 weights need m <= 2, k %% 8 == 0, scales and 8-byte aligned rows (m=%d k=%d)", a->m, a->k);
+  }
   else return vv_set_error(VV_E_ARG, "vv_linear: bad wdt %d", a->wdt);
   if (rc) return rc;
   if (prof) { (void)hipEventRecord(pr.e1, s); g_prof.push_back(pr); }

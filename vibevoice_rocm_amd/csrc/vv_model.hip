@@ -33,6 +33,13 @@ inline vv_lin_args lin_base(const float* x, int64_t ldx, int m, const void* w, i
 // ---------------------------------------------------------------------------------------------------------------
 // Qwen2 decoder stack
 // ---------------------------------------------------------------------------------------------------------------
+// weight-only fp8 companions (vv_w8) replace the bf16 matrix on the weight-streaming GEMVs (<= 2 activation rows)
+static inline void use_w8(vv_lin_args& a, const vv_w8& q, const vv_w8* q2 = nullptr) {
+  if (a.m > 2 || !q.q || !q.scale || (a.w2 && (!q2 || !q2->q || !q2->scale))) return;
+  a.w = q.q; a.wscale = q.scale; a.wdt = VV_FP8;
+  if (a.w2) { a.w2 = q2->q; a.w2scale = q2->scale; }
+}
+
 // from this many rows on, a bf16-weight LLM forward is a prompt prefill: activations are cast to bf16 once per GEMM and both
 // operands stream from global on the matrix cores with 128-row tiles (every weight fragment reused by 4 row tiles)
 #define VV_PREFILL_ROWS 64
@@ -73,6 +80,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     } else {
       a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
       a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
+      use_w8(a, L.q_qkv);
     }
     VV_TRY(vv_linear(&a, stream));
     if (cache_rows == nullptr && R <= kv->rows) {
@@ -87,6 +95,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       a.flags = VV_LIN_X_BF16;
     } else {
       a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
+      use_w8(a, L.q_o);
     }
     a.res = h; a.ldres = H;
     VV_TRY(vv_linear(&a, stream));
@@ -99,6 +108,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln2; a.eps = m->rms_eps;
     }
     a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
+    if (!prefill) use_w8(a, L.q_gate, &L.q_up);
     VV_TRY(vv_linear(&a, stream));
     if (prefill) {
       VV_TRY(vv_cast_rows_bf16(act, m->inter, R, m->inter, VV_PRO_NONE, nullptr, 0.f, xb, m->inter, stream));
@@ -106,6 +116,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       a.flags = VV_LIN_X_BF16;
     } else {
       a = lin_base(act, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
+      use_w8(a, L.q_down);
     }
     a.res = h; a.ldres = H;
     VV_TRY(vv_linear(&a, stream));
@@ -141,9 +152,11 @@ static int head_body(const vv_head* h, const float* x, int64_t ldx, int R, float
     a.pro = VV_PRO_RMSNORM; a.norm_w = L.norm_w; a.eps = h->eps;
     a.mod_shift = ml; a.mod_scale = ml + D; a.ld_mod = 3 * D;
     a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
+    use_w8(a, L.q_gate, &L.q_up);
     VV_TRY(vv_linear(&a, stream));
     a = lin_base(act, h->ffn, R, L.wdown, D, h->ffn, h->wdt, hcur, D);
     a.gate = ml + 2 * D; a.gate_ld = 3 * D; a.res = hcur; a.ldres = D;
+    use_w8(a, L.q_down);
     VV_TRY(vv_linear(&a, stream));
   }
   const float* mf = modf + mrow * 2 * D;
@@ -290,11 +303,13 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     vv_lin_args a = lin_base(other, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
     a.pro = VV_PRO_RMSNORM; a.norm_w = B.ffn_norm_w; a.eps = net->eps; a.bias = B.b1; a.act = VV_ACT_GELU;
     if (handoff) a.flags |= VV_LIN_OUT_BF16;
+    use_w8(a, B.q_w1);
     VV_TRY(vv_linear(&a, stream));
     float* dst = (j == nb - 1 && final_dst) ? final_dst : other;
     a = lin_base(hid, 4 * C, (int)T, B.w2, C, 4 * C, net->wdt, dst, C);
     if (handoff) a.flags |= VV_LIN_X_BF16;
     a.bias = B.b2; a.gate = B.ffn_gamma; a.gate_ld = 0; a.res = other; a.ldres = C;
+    use_w8(a, B.q_w2);
     VV_TRY(vv_linear(&a, stream));
     if (dst == other) { float* t = cur; cur = other; other = t; }   // result now in `cur`
     else { cur = nullptr; }                                           // result went to final_dst

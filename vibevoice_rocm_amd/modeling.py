@@ -79,7 +79,7 @@ def _make_sampler(gen_cfg: dict):
 
 class VibeVoiceForConditionalGenerationInference:
     def __init__(self, config: VVConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", torch_dtype=torch.bfloat16,
-                 attn_implementation: str = "hip_gfx950", use_graphs: bool = True):
+                 attn_implementation: str = "hip_gfx950", use_graphs: bool = True, weight_quant: Optional[str] = None):
         missing = [k for k in state_dict_shapes(config) if k not in state_dict]
         if missing:
             raise KeyError(f"state dict is missing {len(missing)} tensors, e.g. {missing[:4]}")
@@ -88,7 +88,9 @@ class VibeVoiceForConditionalGenerationInference:
         # launch a frame's diffusion tail right behind the LLM step while the host still waits for the token (rolled back when the
         # token is not speech_diffusion); results are identical either way (tests/test_hip_parity.py)
         self.speculative_frames = True
-        self.engine = Engine(config, state_dict, device=device, dtype=torch_dtype, use_graphs=use_graphs)
+        # weight_quant="fp8": weight-only e4m3 companions for the per-frame weight-streaming GEMVs
+        self.weight_quant = weight_quant
+        self.engine = Engine(config, state_dict, device=device, dtype=torch_dtype, use_graphs=use_graphs, weight_quant=weight_quant)
         self.device = self.engine.device
         self.ddpm_inference_steps = config.ddpm_infer
         # attribute paths the reference's callers read
@@ -110,7 +112,8 @@ class VibeVoiceForConditionalGenerationInference:
         if str(device) == "cuda":
             device = "cuda:0"
         return cls(cfg, load_state_dict_from_dir(path), device=device, torch_dtype=torch_dtype,
-                   attn_implementation=attn_implementation or "hip_gfx950", use_graphs=kw.get("use_graphs", True))
+                   attn_implementation=attn_implementation or "hip_gfx950", use_graphs=kw.get("use_graphs", True),
+                   weight_quant=kw.get("weight_quant"))
 
     @classmethod
     def from_synthetic(cls, config: VVConfig, seed: int = 1234, device="cuda:0", torch_dtype=torch.bfloat16, numpy_weights=False, **kw):

@@ -29,11 +29,59 @@ def _wdt(dtype: torch.dtype) -> int:
     raise ValueError(f"unsupported weight dtype {dtype}")
 
 
+FP8_MAX = 448.0      # largest finite e4m3fn magnitude
+
+
+def quantize_e4m3_pow2(w: torch.Tensor):
+    """Weight-only fp8 of a [N, K] matrix: one POWER-OF-TWO scale per output row (2^ceil(log2(amax / 448))) and round-to-nearest
+    e4m3fn codes.  With a power-of-two scale the dequantised weight code * scale is exactly representable in bf16, so the bf16
+    copy the GEMM-shaped uses keep (prefill, T > 4) and the fp8 copy the decode GEMVs stream are the SAME effective matrix.
+    Returns (codes uint8 [N, K], scale fp32 [N], effective weights fp32 [N, K])."""
+    wf = w.detach().float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / FP8_MAX)))
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.contiguous(), q.float() * scale[:, None]
+
+
+def fp8_matrix_names(cfg: VVConfig):
+    """State-dict keys of the matrices that run as weight-streaming GEMVs every frame and get an fp8 companion: the LLM's linears,
+    the diffusion head's SwiGLU matrices, the FFN linears of the 1-row conv stage (decoder stage 0 / semantic-encoder last stage)."""
+    names = []
+    for l in range(cfg.layers):
+        q = f"model.language_model.layers.{l}."
+        names += [q + f"self_attn.{n}_proj.weight" for n in "qkvo"] + [q + f"mlp.{n}_proj.weight" for n in ("gate", "up", "down")]
+    for l in range(cfg.head_layers):
+        q = f"model.prediction_head.layers.{l}."
+        names += [q + f"ffn.{n}_proj.weight" for n in ("gate", "up", "down")]
+    n_st = len(cfg.ac_ratios) + 1
+    for j in range(cfg.ac_depths[-1]):
+        names += [f"model.acoustic_tokenizer.decoder.stages.0.{j}.ffn.linear{i}.weight" for i in (1, 2)]
+    for j in range(cfg.sem_depths[-1]):
+        names += [f"model.semantic_tokenizer.encoder.stages.{n_st - 1}.{j}.ffn.linear{i}.weight" for i in (1, 2)]
+    return names
+
+
+def fp8_effective_state_dict(cfg: VVConfig, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The state dict a weight_quant="fp8" engine computes with (for the checker side of parity tests): the listed matrices replaced
+    by code * scale (q/k/v are quantised as the fused [q|k|v] matrix, row scales make that identical to quantising them apart)."""
+    out = dict(sd)
+    for name in fp8_matrix_names(cfg):
+        out[name] = quantize_e4m3_pow2(sd[name])[2].to(sd[name].dtype if sd[name].dtype == torch.float32 else torch.float32)
+    return out
+
+
 class DeviceWeights:
     """Owns every device tensor of the model and the C descriptors (vv_llm, vv_head, vv_convnet x3, vv_connector x2)."""
 
-    def __init__(self, cfg: VVConfig, sd: Dict[str, torch.Tensor], device, wdtype=torch.bfloat16, streaming_state=True):
+    def __init__(self, cfg: VVConfig, sd: Dict[str, torch.Tensor], device, wdtype=torch.bfloat16, streaming_state=True, quant=None):
         self.cfg, self.device, self.wdtype = cfg, torch.device(device), wdtype
+        if quant not in (None, "fp8"):
+            raise ValueError(f"weight_quant {quant!r}: only None or 'fp8' (weight-only e4m3, decode GEMVs) is built")
+        if quant == "fp8" and wdtype != torch.bfloat16:
+            raise ValueError("weight_quant='fp8' keeps bf16 copies for the GEMM-shaped uses: torch_dtype must be bfloat16")
+        self.quant = quant
+        self._fp8_names = set(fp8_matrix_names(cfg)) if quant == "fp8" else set()
         self.wdt = _wdt(wdtype)
         self._keep: List[object] = []     # tensors / ctypes arrays that must outlive the descriptors
         self._sd = sd
@@ -70,6 +118,17 @@ class DeviceWeights:
         self._keep.append(t)
         return t
 
+    def _mat_q(self, t: torch.Tensor, quantise: bool):
+        """(bf16 matrix, vv_w8 companion): in fp8 mode the bf16 copy holds the dequantised values (exact, power-of-two scales)."""
+        w8 = L.W8()
+        if not (quantise and self.quant == "fp8"):
+            return self._mat(t), w8
+        codes, scale, eff = quantize_e4m3_pow2(t.to(self.device))
+        codes = self._aligned(codes.to(self.device))
+        self._keep.append(codes)
+        w8.q, w8.scale = L.ptr(codes), L.ptr(self._vec(scale))
+        return self._mat(eff), w8
+
     def _vec(self, t: torch.Tensor) -> torch.Tensor:
         t = self._aligned(t.detach().to(device=self.device, dtype=torch.float32).contiguous())
         self._keep.append(t)
@@ -104,18 +163,20 @@ class DeviceWeights:
         layers = (L.LlmLayer * cfg.layers)()
         for l in range(cfg.layers):
             q = f"{p}layers.{l}."
-            wqkv = self._mat(torch.cat([sd[q + "self_attn.q_proj.weight"], sd[q + "self_attn.k_proj.weight"],
-                                        sd[q + "self_attn.v_proj.weight"]], dim=0))
+            qz = self.quant == "fp8"
+            lay = layers[l]
+            wqkv, lay.q_qkv = self._mat_q(torch.cat([sd[q + "self_attn.q_proj.weight"], sd[q + "self_attn.k_proj.weight"],
+                                                    sd[q + "self_attn.v_proj.weight"]], dim=0), qz)
             bqkv = self._vec(torch.cat([sd[q + "self_attn.q_proj.bias"], sd[q + "self_attn.k_proj.bias"],
                                         sd[q + "self_attn.v_proj.bias"]], dim=0))
-            lay = layers[l]
             lay.ln1 = L.ptr(self._vec(sd[q + "input_layernorm.weight"]))
             lay.ln2 = L.ptr(self._vec(sd[q + "post_attention_layernorm.weight"]))
             lay.wqkv, lay.bqkv = L.ptr(wqkv), L.ptr(bqkv)
-            lay.wo = L.ptr(self._mat(sd[q + "self_attn.o_proj.weight"]))
-            lay.wgate = L.ptr(self._mat(sd[q + "mlp.gate_proj.weight"]))
-            lay.wup = L.ptr(self._mat(sd[q + "mlp.up_proj.weight"]))
-            lay.wdown = L.ptr(self._mat(sd[q + "mlp.down_proj.weight"]))
+            for field, qf, key in (("wo", "q_o", "self_attn.o_proj.weight"), ("wgate", "q_gate", "mlp.gate_proj.weight"),
+                                   ("wup", "q_up", "mlp.up_proj.weight"), ("wdown", "q_down", "mlp.down_proj.weight")):
+                wm, w8 = self._mat_q(sd[q + key], qz)
+                setattr(lay, field, L.ptr(wm))
+                setattr(lay, qf, w8)
         # Qwen2RotaryEmbedding.compute_default_rope_parameters, same fp32 ops as the reference stack
         inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float) / cfg.head_dim))
         self.inv_freq = self._vec(inv_freq)
@@ -137,9 +198,11 @@ class DeviceWeights:
             q = f"{p}layers.{l}."
             lay = layers[l]
             lay.norm_w = L.ptr(self._vec(sd[q + "norm.weight"]))
-            lay.wgate = L.ptr(self._mat(sd[q + "ffn.gate_proj.weight"]))
-            lay.wup = L.ptr(self._mat(sd[q + "ffn.up_proj.weight"]))
-            lay.wdown = L.ptr(self._mat(sd[q + "ffn.down_proj.weight"]))
+            for field, qf, key in (("wgate", "q_gate", "ffn.gate_proj.weight"), ("wup", "q_up", "ffn.up_proj.weight"),
+                                   ("wdown", "q_down", "ffn.down_proj.weight")):
+                wm, w8 = self._mat_q(sd[q + key], self.quant == "fp8")
+                setattr(lay, field, L.ptr(wm))
+                setattr(lay, qf, w8)
             lay.adaln = L.ptr(self._mat(sd[q + "adaLN_modulation.1.weight"]))
         h = L.Head()
         h.wdt, h.D, h.ffn, h.layers, h.latent, h.cond_dim = self.wdt, cfg.head_hidden, cfg.head_ffn, cfg.head_layers, cfg.latent, cfg.hidden
@@ -192,8 +255,11 @@ class DeviceWeights:
             b.ffn_norm_w = L.ptr(self._vec(sd[q + "ffn_norm.weight"]))
             b.dw_w = L.ptr(self._vec(sd[q + "mixer.conv.conv.conv.weight"].reshape(ch, 7)))
             b.dw_b = L.ptr(self._vec(sd[q + "mixer.conv.conv.conv.bias"]))
-            b.w1, b.b1 = L.ptr(self._mat(sd[q + "ffn.linear1.weight"])), L.ptr(self._vec(sd[q + "ffn.linear1.bias"]))
-            b.w2, b.b2 = L.ptr(self._mat(sd[q + "ffn.linear2.weight"])), L.ptr(self._vec(sd[q + "ffn.linear2.bias"]))
+            qz = state_key is not None and (q + "ffn.linear1.weight") in self._fp8_names
+            w1m, b.q_w1 = self._mat_q(sd[q + "ffn.linear1.weight"], qz)
+            w2m, b.q_w2 = self._mat_q(sd[q + "ffn.linear2.weight"], qz)
+            b.w1, b.b1 = L.ptr(w1m), L.ptr(self._vec(sd[q + "ffn.linear1.bias"]))
+            b.w2, b.b2 = L.ptr(w2m), L.ptr(self._vec(sd[q + "ffn.linear2.bias"]))
             if state_key is not None:
                 h = self._state_zeros(6, ch)
                 self.state_tensors[state_key].append(h)
