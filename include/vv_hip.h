@@ -204,7 +204,7 @@ typedef struct vv_head {
   const vv_head_layer* layer; /* (host) array */
 } vv_head;
 
-typedef struct vv_dpm_coef { float alpha_s, sigma_s, cx, cd, rinv; int order; } vv_dpm_coef;
+typedef struct vv_dpm_coef { float alpha_s, sigma_s, cx, cd, rinv; int order; float cn; /* variance-noise coefficient: 0 for the ODE solver, sigma_t sqrt(1 - e^-2h) for sde-dpmsolver++ */ } vv_dpm_coef;
 
 /* out[(i*rows_b + j), :] = silu(a[j, :] + b[i, :]): the adaLN input silu(cond_proj(cond) + t_emb(t_i)) for all steps at once */
 int vv_add_rows_silu(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream);
@@ -212,7 +212,8 @@ int vv_add_rows_silu(const float* a, int64_t lda, const float* b, int64_t ldb, f
  * m_out = x0 prediction, and h[r, :] = W x_out for r < rows (the next step's noisy_images_proj; W == NULL: skipped).
  * x_in/x_out and m_in/m_out must be distinct buffers. */
 int vv_dpm_proj(const float* v, int64_t ldv, float cfg_scale, const vv_dpm_coef* coef, const float* x_in, const float* m_in,
-                float* x_out, float* m_out, const void* w, int wdt, int latent, int D, float* h, int64_t ldh, int rows, vv_stream_t stream);
+                float* x_out, float* m_out, const void* w, int wdt, int latent, int D, float* h, int64_t ldh, int rows,
+                const float* step_noise /* [latent] variance noise of this step (coef->cn != 0) or NULL */, vv_stream_t stream);
 
 size_t vv_head_ws_bytes(const vv_head* h, int n_steps);
 /* sample_speech_tokens for ONE utterance (modeling_vibevoice_inference.py:695-708) with
@@ -222,7 +223,9 @@ size_t vv_head_ws_bytes(const vv_head* h, int n_steps);
  *   (step-invariant, precomputed by the host with vv_linear); coef (host) per step.  latent_out[latent].
  * cond_proj and every adaLN modulation are hoisted out of the step loop (they do not depend on x). */
 int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_cond, const float* noise, const float* temb,
-                   const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, void* ws, vv_stream_t stream);
+                   const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, void* ws,
+                   const float* sde_noise /* [n_steps, latent] per-step variance noise of the SDE solver (dpm_solver.py:993-998) or NULL */,
+                   vv_stream_t stream);
 /* VibeVoiceDiffusionHead.forward alone (parity tests): x[R, latent], temb_rows[R, D], cond[R, cond_dim] -> v[R, latent] */
 int vv_head_forward(const vv_head* h, const float* x, const float* temb_rows, const float* cond, int R, float* v,
                     void* ws, vv_stream_t stream);

@@ -114,10 +114,12 @@ def _alpha_sigma(sigma: Tensor):
     return alpha_t, sigma * alpha_t
 
 
-def dpm_coefficients(sigmas: Tensor) -> List[dict]:
+def dpm_coefficients(sigmas: Tensor, algorithm: str = "dpmsolver++") -> List[dict]:
     """Per-step scalar coefficients, computed with fp32 0-dim tensors exactly as the reference does.
     convert_model_output dpm_solver.py:581-584; first order :669-677; second order midpoint :738-764;
-    order selection :976-1003 (solver_order 2, final_sigmas_type zero => last step first order)."""
+    order selection :976-1003 (solver_order 2, final_sigmas_type zero => last step first order).
+    algorithm "sde-dpmsolver++" (main.py:543-548): same update shape with cx = sigma_t/sigma_s e^-h, cd = -alpha_t (1 - e^-2h) and
+    a noise term cn = sigma_t sqrt(1 - e^-2h) (dpm_solver.py:680-686 first order, :785-793 second order midpoint)."""
     n = sigmas.shape[0] - 1
     out = []
     for i in range(n):
@@ -128,7 +130,13 @@ def dpm_coefficients(sigmas: Tensor) -> List[dict]:
         h = lam_t - lam_s0
         c = dict(alpha_s=float(a_s0), sigma_s=float(s_s0),          # x0 = alpha_s*x - sigma_s*v
                  cx=float(s_t / s_s0), cd=float(a_t * (torch.exp(-h) - 1.0)),
-                 order=1, rinv=0.0)
+                 order=1, rinv=0.0, cn=0.0)
+        if algorithm == "sde-dpmsolver++":
+            c["cx"] = float(s_t / s_s0 * torch.exp(-h))
+            c["cd"] = float(-(a_t * (1 - torch.exp(-2.0 * h))))
+            c["cn"] = float(s_t * torch.sqrt(1.0 - torch.exp(-2 * h)))
+        elif algorithm != "dpmsolver++":
+            raise ValueError(algorithm)
         first = i == 0
         last = i == n - 1
         if not (first or last):
@@ -142,14 +150,16 @@ def dpm_coefficients(sigmas: Tensor) -> List[dict]:
     return out
 
 
-def dpm_step(c: dict, x: Tensor, v: Tensor, m_prev: Optional[Tensor]):
-    """One scheduler.step in fp32: returns (x_next, x0_pred).  dpm_solver.py:935-1022."""
+def dpm_step(c: dict, x: Tensor, v: Tensor, m_prev: Optional[Tensor], noise: Optional[Tensor] = None):
+    """One scheduler.step in fp32: returns (x_next, x0_pred).  dpm_solver.py:935-1022.  `noise`: the variance noise of the SDE variant."""
     x0 = c["alpha_s"] * x - c["sigma_s"] * v
     if c["order"] == 1:
         x_t = c["cx"] * x - c["cd"] * x0
     else:
         d1 = c["rinv"] * (x0 - m_prev)
         x_t = c["cx"] * x - c["cd"] * x0 - 0.5 * c["cd"] * d1
+    if c.get("cn", 0.0) != 0.0:
+        x_t = x_t + c["cn"] * noise
     return x_t, x0
 
 
@@ -188,11 +198,13 @@ def head_forward(W: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, cond: Te
 
 
 def sample_speech_tokens(W, cfg, cond: Tensor, ncond: Tensor, noise: Tensor, cfg_scale: float, n_steps: int,
-                         tables=None) -> Tensor:
+                         tables=None, algorithm: str = "dpmsolver++", sde_noise: Optional[Tensor] = None) -> Tensor:
     """CFG DPM-Solver++ sampling loop with INJECTED noise [n, latent] (the reference draws
-    randn(2n, latent) on the CPU and only ever uses rows [:n]).  modeling_vibevoice_inference.py:695-708."""
+    randn(2n, latent) on the CPU and only ever uses rows [:n]).  modeling_vibevoice_inference.py:695-708.
+    SDE variant: `sde_noise` [n_steps, n, latent] = rows [:n] of the [2n, latent] variance noise scheduler.step draws per step
+    (dpm_solver.py:993-998); rows [n:] only ever perturb the half of the batch that the next iteration throws away."""
     if tables is None:
-        tables = make_dpm_tables(cfg, n_steps)
+        tables = make_dpm_tables(cfg, n_steps, algorithm)
     timesteps, coefs = tables
     n = cond.shape[0]
     condition = torch.cat([cond, ncond], dim=0).float()
@@ -204,14 +216,14 @@ def sample_speech_tokens(W, cfg, cond: Tensor, ncond: Tensor, noise: Tensor, cfg
         eps = head_forward(W, cfg, combined, tt, condition)
         ce, ue = eps[:n], eps[n:]
         half = ue + cfg_scale * (ce - ue)
-        x, m_prev = dpm_step(coefs[i], x, half, m_prev)
+        x, m_prev = dpm_step(coefs[i], x, half, m_prev, None if sde_noise is None else sde_noise[i].float())
     return x
 
 
-def make_dpm_tables(cfg: dict, n_steps: int):
+def make_dpm_tables(cfg: dict, n_steps: int, algorithm: str = "dpmsolver++"):
     ac = cosine_alphas_cumprod(cfg["ddpm_steps"])
     timesteps, sigmas = dpm_set_timesteps(ac, n_steps)
-    return timesteps, dpm_coefficients(sigmas)
+    return timesteps, dpm_coefficients(sigmas, algorithm)
 
 
 # --------------------------------------------------------------------------------------

@@ -168,7 +168,7 @@ def test_dpm_step_and_fused_boundary_agree(lib):
         xo, mo, h = torch.zeros(latent, device="cuda"), torch.zeros(latent, device="cuda"), torch.zeros(2, D, device="cuda")
         Wd, xi, mi = W.cuda(), x.cuda(), mp.cuda()
         L.check(l.vv_dpm_proj(vd.data_ptr(), latent, 2.0, C.byref(c), xi.data_ptr(), mi.data_ptr(), xo.data_ptr(), mo.data_ptr(),
-                              Wd.data_ptr(), L.VV_F32, latent, D, h.data_ptr(), D, 2, None), "dpm_proj")
+                              Wd.data_ptr(), L.VV_F32, latent, D, h.data_ptr(), D, 2, None, None), "dpm_proj")
         torch.cuda.synchronize()
         assert rel_rms(xd.cpu().numpy(), ref.numpy()) < 1e-6 and rel_rms(xo.cpu().numpy(), ref.numpy()) < 1e-6
         assert rel_rms(md.cpu().numpy(), x0.numpy()) < 1e-6 and rel_rms(mo.cpu().numpy(), x0.numpy()) < 1e-6
@@ -373,10 +373,78 @@ def test_sample_speech_tokens_vs_reference(tiny_engine):
                 eng.hidden2[1].copy_(dev(g["ncond"][0]))
                 eng.noise_dev.copy_(dev(g["noise"][0]))
                 eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), eng.cfg.hidden, eng.noise_dev.data_ptr(),
-                                               eng.temb.data_ptr(), eng._coefs, n, cs, eng.latent.data_ptr(), eng._head_ws.data_ptr(), eng.sp),
+                                               eng.temb.data_ptr(), eng._coefs, n, cs, eng.latent.data_ptr(), eng._head_ws.data_ptr(), None, eng.sp),
                         "vv_head_sample")
             eng.stream.synchronize()
             assert rel_rms(eng.latent.cpu().numpy(), g[f"latent_n{n}_cfg{cs}"][0]) < 3e-4, (n, cs)
+
+
+def test_sample_speech_tokens_sde_solver_vs_reference(tiny_engine):
+    """The SDE solver main.py selects (scheduler.from_config(algorithm_type="sde-dpmsolver++", beta_schedule="squaredcos_cap_v2"),
+    main.py:543-548) against the reference's own sample_speech_tokens with the variance noise replayed."""
+    from vibevoice_rocm_amd.schedule import DPMSolverMultistepScheduler
+    eng = tiny_engine
+    g = load_golden("sample_sde_tiny")
+    ode = eng.scheduler
+    eng.scheduler = DPMSolverMultistepScheduler.from_config(ode.config, algorithm_type="sde-dpmsolver++", beta_schedule="squaredcos_cap_v2")
+    try:
+        for n in (10, 20):
+            eng.set_steps(n)
+            assert eng.sde and eng._coefs[0].cn > 0 and eng._coefs[n - 1].cn == 0.0
+            with torch.cuda.stream(eng.stream):
+                eng.hidden2[0].copy_(dev(g["cond"][0]))
+                eng.hidden2[1].copy_(dev(g["ncond"][0]))
+                eng.noise_dev.copy_(dev(g["noise"][0]))
+                eng.sde_noise_dev.copy_(dev(g[f"step_noise_n{n}"][:, 0]))
+                eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), eng.cfg.hidden, eng.noise_dev.data_ptr(),
+                                               eng.temb.data_ptr(), eng._coefs, n, 1.5, eng.latent.data_ptr(), eng._head_ws.data_ptr(),
+                                               eng.sde_noise_dev.data_ptr(), eng.sp), "vv_head_sample")
+            eng.stream.synchronize()
+            assert rel_rms(eng.latent.cpu().numpy(), g[f"latent_n{n}"][0]) < 3e-4, n
+            # a step with a noise coefficient but no noise is refused, never silently run as the ODE solver
+            assert eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), eng.cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(),
+                                          eng._coefs, n, 1.5, eng.latent.data_ptr(), eng._head_ws.data_ptr(), None, eng.sp) != 0
+    finally:
+        eng.scheduler = ode
+        eng.set_steps(10)
+
+
+def test_generate_with_sde_solver_mid_vs_oracle(mid):
+    """generate() after the main.py scheduler swap, bf16 'mid' preset, injected initial + variance noise, against the oracle."""
+    from oracle import vv_oracle as O
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    cfg, sd = mid
+    sd_o = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    V = cfg.vocab
+    ST, E, D, EOS = V - 4, V - 3, V - 2, V - 1
+    g = torch.Generator().manual_seed(21)
+    noise, sde_noise = torch.randn(3, cfg.latent, generator=g), torch.randn(3, 10, cfg.latent, generator=g)
+    cond, ncond = torch.randn(1, cfg.hidden, generator=g), torch.randn(1, cfg.hidden, generator=g)
+    m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
+    m.engine.bf16_t_quirk = False
+    m.model.noise_scheduler = m.model.noise_scheduler.from_config(m.model.noise_scheduler.config, algorithm_type="sde-dpmsolver++",
+                                                                  beta_schedule="squaredcos_cap_v2")
+    m.set_ddpm_inference_steps(num_steps=10)
+    eng = m.engine
+    assert eng.sde
+    W = {k[len("model.prediction_head."):]: v for k, v in sd_o.items() if k.startswith("model.prediction_head.")}
+    W = {"model.prediction_head." + k: v for k, v in W.items()}
+    want = O.sample_speech_tokens(sd_o, cfg.as_dict(), cond, ncond, noise[:1], 1.5, 10, algorithm="sde-dpmsolver++", sde_noise=sde_noise[0][:, None])
+    with torch.cuda.stream(eng.stream):
+        eng.hidden2[0].copy_(cond[0].cuda()); eng.hidden2[1].copy_(ncond[0].cuda())
+    eng.cfg_scale = 1.5
+    eng.step_speech(noise[0], sde_noise[0])
+    eng.stream.synchronize()
+    assert rel_rms(eng.latent.cpu().numpy(), want[0].numpy()) < 2e-2
+    # whole loop: speculative and plain launches agree bit for bit with the SDE noise in play, and differ from the ODE solver
+    ids = torch.randint(0, V - 8, (20,), generator=g)
+    forced = [ST, D, D, E, ST, D, EOS]
+    outs = []
+    for spec in (False, True):
+        m.speculative_frames = spec
+        o = m.generate(input_ids=ids[None], tokenizer=_Tok(ST, E, D, EOS), cfg_scale=1.5, forced_tokens=forced, noise=noise, sde_noise=sde_noise)
+        outs.append(o.speech_outputs[0][0].cpu().numpy())
+    assert outs[0].shape == (3 * cfg.hop,) and np.array_equal(outs[0], outs[1])
 
 
 def test_decoder_streaming_vs_reference(tiny_engine):

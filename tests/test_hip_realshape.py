@@ -46,7 +46,7 @@ def test_head_sampling_1p5b_vs_oracle(big):
     with torch.cuda.stream(eng.stream):
         eng.hidden2[0].copy_(cond[0].cuda()); eng.hidden2[1].copy_(ncond[0].cuda()); eng.noise_dev.copy_(noise[0].cuda())
         eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(),
-                                       eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), eng.sp), "vv_head_sample")
+                                       eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), None, eng.sp), "vv_head_sample")
     eng.stream.synchronize()
     per_gemv = eng.latent.cpu().numpy().copy()
     assert rel_rms(per_gemv, ref[0].numpy()) < 2e-2
@@ -58,7 +58,7 @@ def test_head_sampling_1p5b_vs_oracle(big):
             eng.latent.zero_()
             for _ in range(3):    # replays start from the previous launch's epochs: the tags/flags must be reset per launch
                 eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(),
-                                               eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), eng.sp), "vv_head_sample")
+                                               eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), None, eng.sp), "vv_head_sample")
         eng.stream.synchronize()
     finally:
         eng.w.head.flags = 0

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.vv_abi_version() == 1
+    assert lib.vv_abi_version() == 2
 
 
 def test_no_cpu_fallback():
@@ -57,8 +57,13 @@ def test_schedule_matches_reference_tables():
             xn = xn - 0.5 * c["cd"] * (c["rinv"] * (x0 - m_prev))
         x, m_prev = xn, x0
         np.testing.assert_allclose(x.numpy(), g["traj_20"][i], rtol=2e-4, atol=2e-5)
+    # the SDE solver main.py selects is built (noise coefficient > 0 except on the final sigma-0 step); other variants are refused
+    sde = DPMSolverMultistepScheduler.from_config(s.config, algorithm_type="sde-dpmsolver++", beta_schedule="squaredcos_cap_v2")
+    sde.set_timesteps(20)
+    assert all(c["cn"] > 0 for c in sde.coefs[:-1]) and sde.coefs[-1]["cn"] == 0.0 and sde.coefs[-1]["cx"] == 0.0
+    assert all(c["cn"] == 0.0 for c in s.coefs)
     with pytest.raises(NotImplementedError):
-        DPMSolverMultistepScheduler.from_config(s.config, algorithm_type="sde-dpmsolver++")
+        DPMSolverMultistepScheduler.from_config(s.config, algorithm_type="dpmsolver")
     # bf16 quirk of the reference's bf16 run: timesteps are rounded to bf16 before the sinusoid
     assert torch.tensor([949.0]).bfloat16().float().item() == 948.0
     e = timestep_sinusoid([949], 256, bf16_quirk=True)

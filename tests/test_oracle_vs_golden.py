@@ -52,6 +52,19 @@ def test_sample_speech_tokens(tiny_cfg, tiny_weights):
             assert rel_rms(lat.numpy(), g[f"latent_n{n}_cfg{cs}"]) < 1e-4, (n, cs)
 
 
+def test_sample_speech_tokens_sde_solver(tiny_cfg, tiny_weights):
+    """The SDE solver main.py selects (scheduler.from_config(algorithm_type="sde-dpmsolver++"), main.py:543-548): the reference's own
+    sample_speech_tokens with the per-step variance noise replayed from the seeded CPU generator."""
+    g = load_golden("sample_sde_tiny")
+    cfg = tiny_cfg.as_dict()
+    for n in (10, 20):
+        lat = O.sample_speech_tokens(tiny_weights, cfg, t(g["cond"]), t(g["ncond"]), t(g["noise"]), 1.5, n, algorithm="sde-dpmsolver++",
+                                     sde_noise=t(g[f"step_noise_n{n}"]))
+        assert rel_rms(lat.numpy(), g[f"latent_n{n}"]) < 1e-4, n
+        ode = O.sample_speech_tokens(tiny_weights, cfg, t(g["cond"]), t(g["ncond"]), t(g["noise"]), 1.5, n)
+        assert rel_rms(ode.numpy(), g[f"latent_n{n}"]) > 1e-2          # and it is not the ODE solver's answer
+
+
 def test_decoder_streaming_and_full(tiny_cfg, tiny_weights):
     g = load_golden("decoder_tiny")
     cfg = tiny_cfg.as_dict()

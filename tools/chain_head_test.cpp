@@ -69,11 +69,11 @@ int main(int argc, char** argv) {
 
   auto run = [&](int flags, float* out, const char* name, int iters) {
     h.flags = flags;
-    VV(vv_head_sample(&h, cond2, cond_dim, noise, temb, coef, n_steps, 1.3f, out, ws, s));   // eager once
+    VV(vv_head_sample(&h, cond2, cond_dim, noise, temb, coef, n_steps, 1.3f, out, ws, nullptr, s));   // eager once
     CK(hipStreamSynchronize(s));
     void* g = nullptr;
     VV(vv_graph_begin(s));
-    VV(vv_head_sample(&h, cond2, cond_dim, noise, temb, coef, n_steps, 1.3f, out, ws, s));
+    VV(vv_head_sample(&h, cond2, cond_dim, noise, temb, coef, n_steps, 1.3f, out, ws, nullptr, s));
     VV(vv_graph_end(s, &g));
     for (int i = 0; i < 3; ++i) VV(vv_graph_launch(g, s));
     CK(hipStreamSynchronize(s));
@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
     vv_chain_debug_times(t, 1);
     h.flags = VV_HEAD_CHAIN;
     const int reps = 10;
-    for (int i = 0; i < reps; ++i) VV(vv_head_sample(&h, cond2, cond_dim, noise, temb, coef, n_steps, 1.3f, outB, ws, s));
+    for (int i = 0; i < reps; ++i) VV(vv_head_sample(&h, cond2, cond_dim, noise, temb, coef, n_steps, 1.3f, outB, ws, nullptr, s));
     CK(hipStreamSynchronize(s));
     vv_chain_debug_times(t, 1);
     const double ph = 201.0 * reps;

@@ -32,7 +32,7 @@ def timeit(name, fn, reps=50):
     return dt
 tot = 0
 tot += timeit("A: llm step(R=2)+token", lambda: eng._seq_A(V-4, V-2), reps=30)
-def head(): eng._ck(lib.vv_head_sample(C.byref(w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(), eng._coefs, eng.n_steps, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), eng.sp), "h")
+def head(): eng._ck(lib.vv_head_sample(C.byref(w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(), eng._coefs, eng.n_steps, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), None, eng.sp), "h")
 tot += timeit("B1: head sample (20 steps)", head)
 def dec(): eng._ck(lib.vv_decoder_forward(C.byref(w.dec), eng.latent.data_ptr(), 1, 5.0, -0.05, eng.wav.data_ptr(), eng._dec_ws.data_ptr(), eng.sp), "d")
 tot += timeit("B2: acoustic decoder frame", dec)

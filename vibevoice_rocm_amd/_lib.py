@@ -62,7 +62,7 @@ class Head(C.Structure):
 
 class DpmCoef(C.Structure):
     _fields_ = [("alpha_s", C.c_float), ("sigma_s", C.c_float), ("cx", C.c_float), ("cd", C.c_float),
-                ("rinv", C.c_float), ("order", C.c_int)]
+                ("rinv", C.c_float), ("order", C.c_int), ("cn", C.c_float)]
 
 
 class Block(C.Structure):
@@ -110,7 +110,7 @@ PROTOTYPES = {
     "vv_affine": (C.c_int, [vp, C.c_float, C.c_float, vp, i64, vp]),
     "vv_add_rows": (C.c_int, [vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
     "vv_add_rows_silu": (C.c_int, [vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "vv_dpm_proj": (C.c_int, [vp, i64, C.c_float, C.POINTER(DpmCoef), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "vv_dpm_proj": (C.c_int, [vp, i64, C.c_float, C.POINTER(DpmCoef), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp, vp]),
     "vv_embed_row": (C.c_int, [vp, C.c_int, i64, vp, vp, vp]),
     "vv_gather_rows": (C.c_int, [vp, C.c_int, i64, C.POINTER(C.c_int), C.c_int, vp, vp]),
     "vv_argmax_ids": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
@@ -122,7 +122,7 @@ PROTOTYPES = {
     "vv_llm_ws_bytes": (C.c_size_t, [C.POINTER(Llm), C.c_int]),
     "vv_llm_forward": (C.c_int, [C.POINTER(Llm), C.POINTER(KV), vp, i64, C.c_int, vp, vp, vp, i64, vp, vp]),
     "vv_head_ws_bytes": (C.c_size_t, [C.POINTER(Head), C.c_int]),
-    "vv_head_sample": (C.c_int, [C.POINTER(Head), vp, i64, vp, vp, C.POINTER(DpmCoef), C.c_int, C.c_float, vp, vp, vp]),
+    "vv_head_sample": (C.c_int, [C.POINTER(Head), vp, i64, vp, vp, C.POINTER(DpmCoef), C.c_int, C.c_float, vp, vp, vp, vp]),
     "vv_head_forward": (C.c_int, [C.POINTER(Head), vp, vp, vp, C.c_int, vp, vp, vp]),
     "vv_convnet_ws_bytes": (C.c_size_t, [C.POINTER(ConvNet), i64, C.c_int]),
     "vv_decoder_forward": (C.c_int, [C.POINTER(ConvNet), vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]),

@@ -29,7 +29,7 @@ int vv_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* vv_last_error(void) { return g_err; }
-extern "C" int vv_abi_version(void) { return 1; }
+extern "C" int vv_abi_version(void) { return 2; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments
 extern "C" int vv_init(void) {
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
@@ -1211,7 +1211,7 @@ extern "C" int vv_dpm_step(const float* v, int64_t ldv, int n_samples, int laten
 template <typename WT>
 __global__ __launch_bounds__(256) void dpm_proj_kernel(const float* v, int64_t ldv, int has_v, float cfg, vv_dpm_coef k,
                                                        const float* x_in, const float* m_in, float* x_out, float* m_out,
-                                                       const WT* W, int latent, int D, float* h, int64_t ldh, int rows) {
+                                                       const WT* W, int latent, int D, float* h, int64_t ldh, int rows, const float* step_noise) {
   extern __shared__ float xs[];
   const int tid = threadIdx.x;
   for (int i = tid; i < latent; i += blockDim.x) {
@@ -1222,6 +1222,7 @@ __global__ __launch_bounds__(256) void dpm_proj_kernel(const float* v, int64_t l
       const float x0 = k.alpha_s * xn - k.sigma_s * eps;
       float xt = k.cx * xn - k.cd * x0;
       if (k.order == 2) xt -= 0.5f * k.cd * (k.rinv * (x0 - m_in[i]));
+      if (step_noise) xt = fmaf(k.cn, step_noise[i], xt);      // SDE solver: variance noise of this step
       xn = xt;
       if (blockIdx.x == 0) m_out[i] = x0;
     }
@@ -1240,18 +1241,20 @@ __global__ __launch_bounds__(256) void dpm_proj_kernel(const float* v, int64_t l
 
 extern "C" int vv_dpm_proj(const float* v, int64_t ldv, float cfg_scale, const vv_dpm_coef* coef, const float* x_in, const float* m_in,
                            float* x_out, float* m_out, const void* w, int wdt, int latent, int D, float* h, int64_t ldh, int rows,
-                           vv_stream_t stream) {
+                           const float* step_noise, vv_stream_t stream) {
   if (!x_in || !x_out || (v && (!coef || !m_in || !m_out)) || latent <= 0) return vv_set_error(VV_E_ARG, "vv_dpm_proj: bad args");
   if (x_in == x_out || (v && m_in == m_out)) return vv_set_error(VV_E_ARG, "vv_dpm_proj: x/m buffers must be double-buffered");
   if (w && (!h || D <= 0 || rows <= 0)) return vv_set_error(VV_E_ARG, "vv_dpm_proj: bad projection args");
   vv_dpm_coef k;
   memset(&k, 0, sizeof(k));
   if (v) k = *coef;
+  if (v && k.cn != 0.f && !step_noise) return vv_set_error(VV_E_ARG, "vv_dpm_proj: the SDE solver step needs its variance noise");
+  if (!v || k.cn == 0.f) step_noise = nullptr;
   const int blocks = w ? (D + 255) / 256 : 1;
   const size_t lds = (size_t)latent * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (wdt == VV_F32) hipLaunchKernelGGL((dpm_proj_kernel<float>), dim3(blocks), dim3(256), lds, s, v, ldv, v ? 1 : 0, cfg_scale, k, x_in, m_in, x_out, m_out, (const float*)w, latent, D, h, ldh, rows);
-  else hipLaunchKernelGGL((dpm_proj_kernel<bf16_t>), dim3(blocks), dim3(256), lds, s, v, ldv, v ? 1 : 0, cfg_scale, k, x_in, m_in, x_out, m_out, (const bf16_t*)w, latent, D, h, ldh, rows);
+  if (wdt == VV_F32) hipLaunchKernelGGL((dpm_proj_kernel<float>), dim3(blocks), dim3(256), lds, s, v, ldv, v ? 1 : 0, cfg_scale, k, x_in, m_in, x_out, m_out, (const float*)w, latent, D, h, ldh, rows, step_noise);
+  else hipLaunchKernelGGL((dpm_proj_kernel<bf16_t>), dim3(blocks), dim3(256), lds, s, v, ldv, v ? 1 : 0, cfg_scale, k, x_in, m_in, x_out, m_out, (const bf16_t*)w, latent, D, h, ldh, rows, step_noise);
   VV_CHECK_LAUNCH("vv_dpm_proj");
   return 0;
 }

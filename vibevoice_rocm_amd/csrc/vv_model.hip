@@ -200,7 +200,8 @@ extern "C" int vv_head_forward(const vv_head* h, const float* x, const float* te
 }
 
 extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_cond, const float* noise, const float* temb,
-                              const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, void* ws, vv_stream_t stream) {
+                              const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, void* ws,
+                              const float* sde_noise, vv_stream_t stream) {
   if (!h || !cond2 || !noise || !temb || !coef || !latent_out || !ws) return vv_set_error(VV_E_ARG, "vv_head_sample: null pointer");
   if (n_steps <= 0 || h->layers > 16) return vv_set_error(VV_E_ARG, "vv_head_sample: bad n_steps/layers");
   hipStream_t s = (hipStream_t)stream;
@@ -224,7 +225,7 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
   VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, stream));
   // the whole solver loop as one persistent kernel (vv_chain.hip) when the shapes are covered
-  const int chained = vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
+  const int chained = sde_noise ? 0 : vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
   if (chained < 0) return chained;
   if (chained) return 0;
   for (int i = 0; i <= n_steps; ++i) {
@@ -232,7 +233,8 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
     const float* xin = (i == 0) ? noise : xb[(i - 1) & 1];
     float* xout = (i == n_steps) ? latent_out : xb[i & 1];
     VV_TRY(vv_dpm_proj(i == 0 ? nullptr : v, h->latent, cfg_scale, i == 0 ? nullptr : &coef[i - 1], xin, mb[(i - 1) & 1], xout, mb[i & 1],
-                       i == n_steps ? nullptr : h->noisy_proj, h->wdt, h->latent, D, hcur, D, 2, stream));
+                       i == n_steps ? nullptr : h->noisy_proj, h->wdt, h->latent, D, hcur, D, 2,
+                       (sde_noise && i > 0) ? sde_noise + (size_t)(i - 1) * h->latent : nullptr, stream));
     if (i == n_steps) break;
     VV_TRY(head_body(h, nullptr, 0, 2, mod, modf, 2 * (int64_t)i, hcur, act, v, stream));
   }

@@ -119,14 +119,16 @@ class Engine:
     # ---------------------------------------------------------------------------------------------------------
     def set_steps(self, n_steps: int):
         """set_ddpm_inference_steps: schedule tables + the step-invariant t_embedder(t_i) table [n, D]."""
-        if n_steps == self.n_steps:
+        algo = self.scheduler.config["algorithm_type"]
+        if n_steps == self.n_steps and algo == getattr(self, "_algo", None):
             return
-        self.n_steps = n_steps
+        self.n_steps, self._algo = n_steps, algo
+        self.sde = algo.startswith("sde")            # variance noise per solver step (dpm_solver.py:993-998)
         self.scheduler.set_timesteps(n_steps)
         coefs = (L.DpmCoef * n_steps)()
         for i, c in enumerate(self.scheduler.coefs):
             coefs[i].alpha_s, coefs[i].sigma_s, coefs[i].cx, coefs[i].cd = c["alpha_s"], c["sigma_s"], c["cx"], c["cd"]
-            coefs[i].rinv, coefs[i].order = c["rinv"], c["order"]
+            coefs[i].rinv, coefs[i].order, coefs[i].cn = c["rinv"], c["order"], c["cn"]
         self._coefs = coefs
         D = self.cfg.head_hidden
         with torch.cuda.stream(self.stream):
@@ -136,6 +138,8 @@ class Engine:
             self.linear(sin, self.w.t_mlp0, t1)
             self.linear(t1, self.w.t_mlp2, self.temb, pro=L.PRO_SILU)
             self._head_ws = torch.empty(self.lib.vv_head_ws_bytes(C.byref(self.w.head), n_steps), dtype=torch.uint8, device=self.device)
+            self.sde_noise_dev = torch.zeros(n_steps, self.cfg.latent, dtype=torch.float32, device=self.device)
+        self.sde_noise_host = torch.zeros(2, n_steps, self.cfg.latent, dtype=torch.float32).pin_memory()
         self._drop_graphs()
 
     def linear(self, x, w, out, pro=L.PRO_NONE, bias=None):
@@ -248,7 +252,7 @@ class Engine:
         self._ck(lib.vv_copy_rows(blob.data_ptr(), blob.numel(), self._state_snap.data_ptr(), blob.numel(), 1, blob.numel(), self.sp), "snapshot")
         self._ck(lib.vv_head_sample(C.byref(w.head), self.hidden2.data_ptr(), cfg.hidden, self.noise_dev.data_ptr(),
                                     self.temb.data_ptr(), self._coefs, self.n_steps, cfg_scale, self.latent.data_ptr(),
-                                    self._head_ws.data_ptr(), self.sp), "vv_head_sample")
+                                    self._head_ws.data_ptr(), self.sde_noise_dev.data_ptr() if self.sde else None, self.sp), "vv_head_sample")
         self._ck(lib.vv_decoder_forward(C.byref(w.dec), self.latent.data_ptr(), 1, 1.0 / w.speech_scale, -w.speech_bias,
                                         self.wav.data_ptr(), self._dec_ws.data_ptr(), self.sp), "vv_decoder_forward")
         self._ck(lib.vv_encoder_forward(C.byref(w.sem), self.wav.data_ptr(), cfg.hop, self.sem.data_ptr(),
@@ -329,30 +333,39 @@ class Engine:
         self.stream.synchronize()
         return int(self.token_host[0])
 
-    def step_speech(self, noise: torch.Tensor):
-        """Phase B.  `noise` is the CPU fp32 [latent] row the reference would have drawn (modeling_vibevoice_inference.py:699)."""
+    def _upload_noise(self, noise: torch.Tensor, sde_noise: Optional[torch.Tensor]):
+        """Host staging (double-buffered pinned rows: the host runs up to a frame ahead) + async copies on the engine stream."""
         self._noise_k ^= 1
         nh = self.noise_host[self._noise_k]
         nh.copy_(noise.reshape(-1)[: self.cfg.latent])
+        self.noise_dev.copy_(nh, non_blocking=True)
+        if self.sde:
+            if sde_noise is None:
+                raise L.VVError("the SDE solver needs the per-step variance noise [n_steps, latent]")
+            sh = self.sde_noise_host[self._noise_k]
+            sh.copy_(sde_noise.reshape(self.n_steps, -1)[:, : self.cfg.latent])
+            self.sde_noise_dev.copy_(sh, non_blocking=True)
+
+    def step_speech(self, noise: torch.Tensor, sde_noise: Optional[torch.Tensor] = None):
+        """Phase B.  `noise` is the CPU fp32 [latent] row the reference would have drawn (modeling_vibevoice_inference.py:699),
+        `sde_noise` [n_steps, latent] the variance noise of the SDE solver's steps (dpm_solver.py:993-998), if that solver is set."""
         with torch.cuda.stream(self.stream):
-            self.noise_dev.copy_(nh, non_blocking=True)
+            self._upload_noise(noise, sde_noise)
             self._run("B", self._seq_B, float(self.cfg_scale))
 
-    def step_decode_speculative(self, tok_start: int, tok_diff: int, forced: Optional[int], noise: torch.Tensor) -> int:
+    def step_decode_speculative(self, tok_start: int, tok_diff: int, forced: Optional[int], noise: torch.Tensor,
+                                sde_noise: Optional[torch.Tensor] = None) -> int:
         """Phase A, then phase B enqueued right behind it ON THE ASSUMPTION that the token is speech_diffusion (the steady state
         of a dialogue), then one host wait on the token alone.  The GPU therefore never idles between A and B while the host
         wakes up and decides; if the token turns out to be something else the caller rolls the speech state back
         (`rollback_speech_state`) - phase B touches nothing else that survives (x2 is rewritten by the embed phase)."""
-        self._noise_k ^= 1
-        nh = self.noise_host[self._noise_k]
-        nh.copy_(noise.reshape(-1)[: self.cfg.latent])
         with torch.cuda.stream(self.stream):
             self.forced_host[0] = -1 if forced is None else int(forced)
             self.forced_dev.copy_(self.forced_host, non_blocking=True)
             self._run("A", self._seq_A, int(tok_start), int(tok_diff))
             self.token_host.copy_(self.token_dev, non_blocking=True)
             self._tok_event.record(self.stream)
-            self.noise_dev.copy_(nh, non_blocking=True)
+            self._upload_noise(noise, sde_noise)
             self._run("B", self._seq_B, float(self.cfg_scale))
         self._tok_event.synchronize()
         return int(self.token_host[0])

@@ -133,6 +133,9 @@ class VibeVoiceForConditionalGenerationInference:
 
     def set_ddpm_inference_steps(self, num_steps=None):
         self.ddpm_inference_steps = num_steps or self.config.ddpm_infer
+        # main.py:543-548 swaps the scheduler first: model.model.noise_scheduler = ....from_config(cfg, algorithm_type="sde-dpmsolver++", ...)
+        if self.model.noise_scheduler is not self.engine.scheduler:
+            self.engine.scheduler = self.model.noise_scheduler
         self.engine.set_steps(self.ddpm_inference_steps)
 
     @property
@@ -203,6 +206,7 @@ class VibeVoiceForConditionalGenerationInference:
         forced_tokens = kwargs.get("forced_tokens")          # extension: bench / fixtures drive the token schedule
         noise = kwargs.get("noise")                          # extension: injected diffusion noise [F, latent]
         speech_noise = kwargs.get("speech_noise")            # extension: (std_noise [S], eps_noise [S, F, 64])
+        sde_noise = kwargs.get("sde_noise")                  # extension: injected variance noise of the SDE solver [F, n_steps, latent]
         input_ids = torch.as_tensor(input_ids)
         if input_ids.dim() == 1:
             input_ids = input_ids[None]
@@ -230,7 +234,8 @@ class VibeVoiceForConditionalGenerationInference:
                     conn_b = conn_all[off: off + n_b]
                     off += n_b
             r = self._generate_one(ids_b, sp_b, conn_b, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
-                                   None if noise is None else torch.as_tensor(noise), audio_streamer, stop_check_fn, b, verbose, sample_fn)
+                                   None if noise is None else torch.as_tensor(noise), audio_streamer, stop_check_fn, b, verbose, sample_fn,
+                                   None if sde_noise is None else torch.as_tensor(sde_noise))
             seqs.append(torch.cat([input_ids[b][~keep], r["sequence"]]))
             audios.append(r["audio"])
             reach.append(r["reach_max"])
@@ -247,8 +252,18 @@ class VibeVoiceForConditionalGenerationInference:
                                          reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
 
     def _generate_one(self, ids: torch.Tensor, sp_mask, conn, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
-                      noise, audio_streamer, stop_check_fn, sample_idx, verbose, sample_fn=None):
+                      noise, audio_streamer, stop_check_fn, sample_idx, verbose, sample_fn=None, sde_noise=None):
         eng, cfg = self.engine, self.config
+
+        def draw(frame):
+            """The frame's random draws, in the reference's order: randn(2, latent) for the initial latent (:699), then - SDE solver
+            only - one randn(2, latent) per solver step (dpm_solver.py:993-998); rows [1:] never reach the result."""
+            nz = noise[frame] if noise is not None else torch.randn(2, cfg.latent)[0]
+            sz = None
+            if eng.sde:
+                sz = sde_noise[frame] if sde_noise is not None else torch.randn(eng.n_steps, 2, cfg.latent)[:, 0]
+            return nz, sz
+
         ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
         valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
         L0 = int(ids.shape[0])
@@ -288,13 +303,14 @@ class VibeVoiceForConditionalGenerationInference:
                 if tok == SD:
                     # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
                     eng.prefill(eng.embed_ids(torch.tensor([ST])), row=1, pos0=0)
-            elif speculate and prev_tok == SD and (noise is None or pending_nz is not None or frame < len(noise)):
+            elif speculate and prev_tok == SD and (pending_nz is not None or ((noise is None or frame < len(noise)) and
+                                                                            (sde_noise is None or frame < len(sde_noise)))):
                 # steady state of a dialogue: the frame's diffusion tail is enqueued right behind the LLM step, the host waits
                 # for the token only.  The noise row is the draw the reference makes when the token IS speech_diffusion; a draw
                 # made for a mis-speculated frame is kept for the next real one (same RNG sequence).
                 if pending_nz is None:
-                    pending_nz = noise[frame] if noise is not None else torch.randn(2, cfg.latent)[0]   # the reference's CPU draw (:699)
-                tok = eng.step_decode_speculative(ST, SD, forced, pending_nz)
+                    pending_nz = draw(frame)
+                tok = eng.step_decode_speculative(ST, SD, forced, *pending_nz)
                 speculated = True
                 if tok != SD:
                     eng.rollback_speech_state()
@@ -314,8 +330,8 @@ class VibeVoiceForConditionalGenerationInference:
             if tok == SD:                                                                       # :571-670
                 if not speculated:
                     if pending_nz is None:
-                        pending_nz = noise[frame] if noise is not None else torch.randn(2, cfg.latent)[0]   # the reference's CPU draw (:699)
-                    eng.step_speech(pending_nz)
+                        pending_nz = draw(frame)
+                    eng.step_speech(*pending_nz)
                 pending_nz = None
                 with torch.cuda.stream(eng.stream):
                     chunk = eng.wav.clone()

@@ -24,10 +24,10 @@ class DPMSolverMultistepScheduler:
                  final_sigmas_type: str = "zero", timestep_spacing: str = "linspace", **unused):
         if beta_schedule not in ("cosine", "squaredcos_cap_v2"):
             raise NotImplementedError(f"beta_schedule {beta_schedule!r}: only the cosine schedule of the shipped configs is built")
-        if prediction_type != "v_prediction" or algorithm_type != "dpmsolver++" or solver_type != "midpoint" \
+        if prediction_type != "v_prediction" or algorithm_type not in ("dpmsolver++", "sde-dpmsolver++") or solver_type != "midpoint" \
                 or solver_order != 2 or final_sigmas_type != "zero" or timestep_spacing != "linspace":
-            raise NotImplementedError("only dpmsolver++ / order 2 / midpoint / v_prediction / linspace / final sigma 0 "
-                                      "(the configuration every shipped model uses) is built")
+            raise NotImplementedError("only dpmsolver++ (every shipped model) and sde-dpmsolver++ (main.py:543-548) / order 2 / midpoint / "
+                                      "v_prediction / linspace / final sigma 0 are built")
         self.config = dict(num_train_timesteps=num_train_timesteps, beta_schedule=beta_schedule, prediction_type=prediction_type,
                            solver_order=solver_order, algorithm_type=algorithm_type, solver_type=solver_type,
                            final_sigmas_type=final_sigmas_type, timestep_spacing=timestep_spacing)
@@ -58,7 +58,7 @@ class DPMSolverMultistepScheduler:
         self.sigmas = torch.from_numpy(sig)
         self.timesteps = torch.from_numpy(ts)
         self.num_inference_steps = len(ts)
-        self.coefs = self._coefficients(self.sigmas)
+        self.coefs = self._coefficients(self.sigmas, self.config["algorithm_type"])
 
     @staticmethod
     def _alpha_sigma(sigma):
@@ -66,7 +66,7 @@ class DPMSolverMultistepScheduler:
         return alpha_t, sigma * alpha_t
 
     @classmethod
-    def _coefficients(cls, sigmas: torch.Tensor) -> List[dict]:
+    def _coefficients(cls, sigmas: torch.Tensor, algorithm: str = "dpmsolver++") -> List[dict]:
         n = sigmas.shape[0] - 1
         out = []
         for i in range(n):
@@ -76,7 +76,11 @@ class DPMSolverMultistepScheduler:
             lam_s0 = torch.log(a_s0) - torch.log(s_s0)
             h = lam_t - lam_s0
             c = dict(alpha_s=float(a_s0), sigma_s=float(s_s0), cx=float(s_t / s_s0),
-                     cd=float(a_t * (torch.exp(-h) - 1.0)), rinv=0.0, order=1)
+                     cd=float(a_t * (torch.exp(-h) - 1.0)), rinv=0.0, order=1, cn=0.0)
+            if algorithm == "sde-dpmsolver++":       # dpm_solver.py:680-686, :785-793: same update shape plus a variance-noise term
+                c["cx"] = float(s_t / s_s0 * torch.exp(-h))
+                c["cd"] = float(-(a_t * (1 - torch.exp(-2.0 * h))))
+                c["cn"] = float(s_t * torch.sqrt(1.0 - torch.exp(-2 * h)))
             if 0 < i < n - 1:            # first step and (final sigma 0) last step are first order
                 a_s1, s_s1 = cls._alpha_sigma(sigmas[i - 1])
                 lam_s1 = torch.log(a_s1) - torch.log(s_s1)
