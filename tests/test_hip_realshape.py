@@ -195,6 +195,17 @@ def test_generate_properties_1p5b(big):
     assert d.speech_outputs[0].shape[-1] == 3 * cfg.hop and st.finished_flags == [True]
     chunks = list(st.get_stream(0))
     assert len(chunks) == 3 and torch.allclose(torch.cat([c.reshape(-1) for c in chunks]), d.speech_outputs[0][0].cpu())
+    # a consumer thread drains the stream while generate() runs to EOS: chunks arrive in order, complete, before the stop signal
+    import threading
+    st2 = AudioStreamer(batch_size=1)
+    got = []
+    th = threading.Thread(target=lambda: got.extend(st2.get_stream(0)), daemon=True)
+    th.start()
+    g2 = m.generate(input_ids=ids[None], tokenizer=tok, cfg_scale=2.0, forced_tokens=[D] * 7 + [E, EOS], noise=torch.randn(8, cfg.latent),
+                    audio_streamer=st2)
+    th.join(timeout=30)
+    assert not th.is_alive() and len(got) == 7
+    assert torch.equal(torch.cat([c.reshape(-1) for c in got]), g2.speech_outputs[0][0].cpu())
     # immediate EOS: no audio
     e = m.generate(input_ids=ids[None], tokenizer=tok, cfg_scale=2.0, forced_tokens=[EOS])
     assert e.speech_outputs[0] is None and e.sequences[0, -1].item() == EOS

@@ -65,6 +65,11 @@ class Engine:
         self.noise_host = torch.zeros(2, cfg.latent, dtype=torch.float32).pin_memory()   # double-buffered: the host runs a frame ahead
         self._noise_k = 0
         self._tok_event = torch.cuda.Event()
+        # streaming delivery: a frame's 3200 samples go device -> pinned ring asynchronously, an event per
+        # slot says when the host may hand them to the AudioStreamer; generate() never blocks the launch queue on a D2H copy
+        self._ring = [torch.zeros(cfg.hop, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._ring_ev = [torch.cuda.Event() for _ in range(4)]
+        self._ring_n = 0
         with torch.cuda.stream(self.stream):
             self._state_snap = torch.empty_like(self.w.state_blob())
         self.scheduler = DPMSolverMultistepScheduler(num_train_timesteps=cfg.ddpm_steps, beta_schedule=cfg.beta_schedule,
@@ -298,7 +303,7 @@ class Engine:
         self.stream.synchronize()
         return self.logits_host[: len(self.valid_ids)].clone()
 
-    def step_decode(self, tok_start: int, tok_diff: int, forced: Optional[int] = None, sample_fn=None) -> int:
+    def step_decode(self, tok_start: int, tok_diff: int, forced: Optional[int] = None, sample_fn=None, on_enqueued=None) -> int:
         """Phase A + the frame's only host sync: returns the chosen token.  With `sample_fn(logits, ids) -> token` (do_sample)
         the constrained logits are read back first and the sampled token is fed to the device-side bookkeeping."""
         if sample_fn is not None and forced is None:
@@ -316,6 +321,8 @@ class Engine:
             self.forced_dev.copy_(self.forced_host, non_blocking=True)
             self._run("A", self._seq_A, int(tok_start), int(tok_diff))
             self.token_host.copy_(self.token_dev, non_blocking=True)
+        if on_enqueued is not None:
+            on_enqueued()
         self.stream.synchronize()
         return int(self.token_host[0])
 
@@ -354,7 +361,7 @@ class Engine:
             self._run("B", self._seq_B, float(self.cfg_scale))
 
     def step_decode_speculative(self, tok_start: int, tok_diff: int, forced: Optional[int], noise: torch.Tensor,
-                                sde_noise: Optional[torch.Tensor] = None) -> int:
+                                sde_noise: Optional[torch.Tensor] = None, on_enqueued=None) -> int:
         """Phase A, then phase B enqueued right behind it ON THE ASSUMPTION that the token is speech_diffusion (the steady state
         of a dialogue), then one host wait on the token alone.  The GPU therefore never idles between A and B while the host
         wakes up and decides; if the token turns out to be something else the caller rolls the speech state back
@@ -367,8 +374,24 @@ class Engine:
             self._tok_event.record(self.stream)
             self._upload_noise(noise, sde_noise)
             self._run("B", self._seq_B, float(self.cfg_scale))
+        if on_enqueued is not None:
+            on_enqueued()          # e.g. hand the previous frame's audio to the streamer: it completes before this step's token
         self._tok_event.synchronize()
         return int(self.token_host[0])
+
+    def stage_chunk(self) -> int:
+        """Enqueue the async D2H copy of the frame just generated into the next ring slot; returns the slot."""
+        k = self._ring_n % len(self._ring)
+        self._ring_n += 1
+        with torch.cuda.stream(self.stream):
+            self._ring[k].copy_(self.wav, non_blocking=True)
+            self._ring_ev[k].record(self.stream)
+        return k
+
+    def take_chunk(self, k: int) -> torch.Tensor:
+        """Wait for slot k's copy and return its samples (a fresh CPU tensor: the slot is reused three frames later)."""
+        self._ring_ev[k].synchronize()
+        return self._ring[k].clone()
 
     def rollback_speech_state(self):
         """Undo the streaming-state updates of the last phase B (a mis-speculated frame)."""

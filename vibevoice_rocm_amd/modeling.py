@@ -283,11 +283,21 @@ class VibeVoiceForConditionalGenerationInference:
         # speculative frame launch needs the greedy / forced token path (a sampled token needs the logits on the host first)
         speculate = self.speculative_frames and sample_fn is None and eng.use_graphs
         prev_tok, pending_nz = None, None
+        staged: List[int] = []          # ring slots whose audio has not been handed to the streamer yet (at most 2)
+
+        def deliver():
+            """Hand finished frames to the streamer.  Called right after the next step's launches are enqueued: the frame's copy
+            completes before that step's token does, so waiting for it here delays nothing on the GPU."""
+            while staged:
+                audio_streamer.put(eng.take_chunk(staged.pop(0))[None, None], stream_idx)
+
+        hook = deliver if audio_streamer is not None else None
         for step in range(max_steps):
             if stop_check_fn is not None and stop_check_fn():                                  # :432-438
                 if verbose:
                     print(f"Generation stopped externally at step {step + 1}")
                 if audio_streamer is not None:
+                    deliver()
                     audio_streamer.end()
                 break
             if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
@@ -310,18 +320,19 @@ class VibeVoiceForConditionalGenerationInference:
                 # made for a mis-speculated frame is kept for the next real one (same RNG sequence).
                 if pending_nz is None:
                     pending_nz = draw(frame)
-                tok = eng.step_decode_speculative(ST, SD, forced, *pending_nz)
+                tok = eng.step_decode_speculative(ST, SD, forced, *pending_nz, on_enqueued=hook)
                 speculated = True
                 if tok != SD:
                     eng.rollback_speech_state()
             else:
-                tok = eng.step_decode(ST, SD, forced, sample_fn)                                # :478-496 (+ speculative :581-583)
+                tok = eng.step_decode(ST, SD, forced, sample_fn, on_enqueued=hook)              # :478-496 (+ speculative :581-583)
             prev_tok = tok
             seq.append(tok)
             if tok == EOS:                                                                      # :517-526
                 if verbose:
                     print(f"Samples [{sample_idx}] reached EOS token at step {step + 1}.", flush=True)
                 if audio_streamer is not None:
+                    deliver()
                     audio_streamer.end(stream_idx)
                 break
             if tok == SE:                                                                       # :540-544
@@ -337,10 +348,14 @@ class VibeVoiceForConditionalGenerationInference:
                     chunk = eng.wav.clone()
                 chunks.append(chunk)
                 if audio_streamer is not None:
-                    audio_streamer.put(chunk[None, None], stream_idx)
+                    staged.append(eng.stage_chunk())
+                    if len(staged) > 2:
+                        deliver()
                 frame += 1
             else:
                 eng.step_embed()                                                                # :567
+        if audio_streamer is not None:
+            deliver()
         eng.stream.synchronize()
         audio = torch.cat(chunks)[None] if chunks else None
         return dict(sequence=torch.tensor(seq, dtype=torch.long), audio=audio, reach_max=reach_max)
