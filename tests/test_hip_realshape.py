@@ -155,6 +155,22 @@ def test_decoder_and_semantic_frames_1p5b_vs_oracle(big):
         assert rel_rms(eng.sem.cpu().numpy(), sem_ref.numpy()) < 2e-2, f
 
 
+def test_voice_prompt_encode_1p5b_vs_oracle(big):
+    """Whole-utterance (non-streaming, zero left padding) acoustic encoder at real shapes on a ragged length: 2 hops + 777 samples ->
+    3 latent frames; the narrow stages run as fused Block1D launches with T = 7177 / 3589 / 1795 rows (not multiples of 32)."""
+    from oracle import vv_oracle as O
+    cfg, sd, m = big
+    eng = m.engine
+    W = _cpu(sd, "model.acoustic_tokenizer.encoder.")
+    g = torch.Generator().manual_seed(8)
+    wav = 0.1 * torch.randn(2 * cfg.hop + 777, generator=g)
+    ref = O.acoustic_encode(W, cfg.as_dict(), wav[None])
+    got = eng.acoustic_encode(wav)
+    eng.stream.synchronize()
+    assert tuple(got.shape) == tuple(ref.shape) == (3, cfg.ac_dim)
+    assert rel_rms(got.cpu().numpy(), ref.numpy()) < 2e-2
+
+
 class _Tok:
     def __init__(self, v):
         self.speech_start_id, self.speech_end_id, self.speech_diffusion_id, self.eos_token_id = v - 4, v - 3, v - 2, v - 1
