@@ -175,6 +175,35 @@ def test_dpm_step_and_fused_boundary_agree(lib):
         assert rel_rms(h[1].cpu().numpy(), (W @ ref).numpy()) < 1e-5 and torch.equal(h[0], h[1])
 
 
+@pytest.mark.parametrize("T,C_", [(1, 2048), (8, 1024), (40, 512), (200, 256), (3, 256), (9, 512), (17, 1024), (256, 256), (300, 256), (5, 96)])
+def test_block_mixer_vs_torch(lib, T, C_):
+    """vv_block_mixer: x + gamma * (dwconv7_causal(RMSNorm(x)) + b), three consecutive streaming calls (history carried) and a
+    stateless call, against torch fp32.  Covers the few-rows kernel (T <= 256, C in 256..2048) and the sliced kernel (the rest)."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(1000 + T + C_)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    nw, dw, db, gm = 1 + r(C_, sc=0.1), r(C_, 7, sc=0.3), r(C_, sc=0.1), r(C_, sc=0.5)
+    eps = 1e-5
+    d = [t.cuda().contiguous() for t in (nw, dw, db, gm)]
+    hist_dev = torch.zeros(6, C_, device="cuda")
+    hist = torch.zeros(6, C_)
+    for call in range(4):
+        x = r(T, C_)
+        streaming = call < 3
+        xn = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps) * nw
+        seq = torch.cat([hist if streaming else torch.zeros(6, C_), xn])
+        want = x + gm * (db + sum(dw[:, k] * seq[k: k + T] for k in range(7)))
+        xd, od = x.cuda(), torch.full((T, C_), float("nan"), device="cuda")
+        L.check(l.vv_block_mixer(xd.data_ptr(), od.data_ptr(), T, C_, d[0].data_ptr(), eps, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                 hist_dev.data_ptr() if streaming else None, None), "vv_block_mixer")
+        torch.cuda.synchronize()
+        assert rel_rms(od.cpu().numpy(), want.numpy()) < 2e-6, (call, T, C_)
+        if streaming:
+            hist = seq[-6:]
+            assert rel_rms(hist_dev.cpu().numpy(), hist.numpy()) < 2e-6, (call, T, C_)
+
+
 @pytest.mark.parametrize("C_", [32, 64, 128])
 @pytest.mark.parametrize("T", [32, 45, 800])
 def test_block1d_single_launch_vs_torch(lib, C_, T):

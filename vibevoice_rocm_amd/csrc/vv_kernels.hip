@@ -30,7 +30,9 @@ int vv_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* vv_last_error(void) { return g_err; }
 extern "C" int vv_abi_version(void) { return 2; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments
+int vv_mixer_init();
 extern "C" int vv_init(void) {
+  VV_TRY(vv_mixer_init());
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
   return vv_chain_init();
@@ -39,11 +41,13 @@ void vv_gemv_stream_set_blocks(int b);
 void vv_gemv_stream_set_dual_rw(int r);
 void vv_gemv_stream_set_small_rw(int r);
 void vv_mfma_set_mt(int mt);
+void vv_mixer_set_rows(int on);
 void vv_mfma_set_mt_prefill(int mt);
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
+  if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "chain_blocks")) { vv_chain_set_blocks(value); return 0; }
   if (key && !strcmp(key, "chain_dbg_mode")) { vv_chain_set_dbg_mode(value); return 0; }
@@ -65,6 +69,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+__device__ __forceinline__ float wave_sum_dpp(float v) { return vv_wave_sum(v); }   // all 64 lanes active
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -1062,11 +1067,155 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
   }
 }
 
+// ---- block mixer, few-rows form (streaming frames of the wide stages: T <= 256 rows, 256 <= C <= 2048) -----------------------------
+// The sliced kernel above is shaped for long sequences (voice prompts): per workgroup it makes ~6 dependent global round trips and
+// recomputes full-row statistics once per channel slice.  A streaming frame of the wide stages is T = 1 / 8 / 40 / 200 rows: here a
+// workgroup owns <= 8 rows x ALL channels, fetches its whole window (6 halo rows) with one batch of loads, reduces each row with
+// DPP wave sums + fixed-order partials in LDS, keeps normalised and raw rows in LDS and writes the result: one global round trip
+// plus the store.  Row tile 0 is the only reader and writer of the history, as above.
+#define MIXR_NI 16                     // float4 a thread may hold: (TR + 6) * C / 4 / 256
+__global__ __launch_bounds__(256) void mixer_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C,
+                                                         const float* __restrict__ norm_w, float eps, const float* __restrict__ dw_w,
+                                                         const float* __restrict__ dw_b, const float* __restrict__ gamma, float* hist, int TR) {
+  extern __shared__ __attribute__((aligned(16))) float msm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C4 = C >> 2;
+  const int t0 = blockIdx.x * TR;
+  const int rows = min(TR, T - t0), nrow = rows + 6;
+  float* xn = msm;                                   // [TR + 6][C] normalised window
+  float* xraw = xn + (size_t)(TR + 6) * C;           // [TR][C] raw rows of this tile (residual)
+  float* part = xraw + (size_t)TR * C;               // [TR + 6][8] per-row partial sums of squares (C4 / 64 slots)
+  const int nel = nrow * C4;                         // float4 elements of the window
+  const int nslot = C4 >> 6;
+  // C <= 1024: 256 % C4 == 0, a thread sees ONE column (4 channels) in every pass: its norm weight, taps, bias and layer scale
+  // are requested up front, next to the window loads, instead of after the reductions
+  const bool colfix = (256 % C4) == 0;
+  const int cfix = 4 * (tid % C4);
+  float4 nwf = make_float4(1.f, 1.f, 1.f, 1.f), dbf = nwf, gmf = nwf;
+  float tapf[28];
+  if (colfix) {
+    nwf = *reinterpret_cast<const float4*>(norm_w + cfix);
+    dbf = *reinterpret_cast<const float4*>(dw_b + cfix);
+    gmf = *reinterpret_cast<const float4*>(gamma + cfix);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const float4 tq = *reinterpret_cast<const float4*>(dw_w + (size_t)cfix * 7 + 4 * q);
+      tapf[4 * q] = tq.x; tapf[4 * q + 1] = tq.y; tapf[4 * q + 2] = tq.z; tapf[4 * q + 3] = tq.w;
+    }
+  }
+  float4 v[MIXR_NI];
+#pragma unroll
+  for (int i = 0; i < MIXR_NI; ++i) {
+    const int e = tid + 256 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < nel) {
+      const int w = e / C4, c4 = e - w * C4, t = t0 - 6 + w;
+      if (t >= 0) v[i] = *reinterpret_cast<const float4*>(x + (int64_t)t * C + 4 * c4);
+      else if (hist) v[i] = *reinterpret_cast<const float4*>(hist + (int64_t)(6 + t) * C + 4 * c4);     // already normalised
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MIXR_NI; ++i) {
+    const int e0 = 256 * i + 64 * wave;              // first element of this wave's 64: one row per wave step (C4 is a multiple of 64)
+    if (e0 < nel) {
+      const float s = wave_sum_dpp(v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
+      const int w = e0 / C4;
+      if (lane == 0) part[w * 8 + ((e0 - w * C4) >> 6)] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MIXR_NI; ++i) {
+    const int e = tid + 256 * i;
+    if (e < nel) {
+      const int w = e / C4, c4 = e - w * C4, t = t0 - 6 + w;
+      float4 o = v[i];
+      if (t >= 0) {
+        float ss = 0.f;
+        for (int sl = 0; sl < nslot; ++sl) ss += part[w * 8 + sl];          // fixed order: deterministic
+        const float rstd = rsqrtf(ss / (float)C + eps);
+        const float4 nw = colfix ? nwf : *reinterpret_cast<const float4*>(norm_w + 4 * c4);
+        o = make_float4(v[i].x * rstd * nw.x, v[i].y * rstd * nw.y, v[i].z * rstd * nw.z, v[i].w * rstd * nw.w);
+        if (w >= 6) *reinterpret_cast<float4*>(xraw + (size_t)(w - 6) * C + 4 * c4) = v[i];
+      }
+      *reinterpret_cast<float4*>(xn + (size_t)w * C + 4 * c4) = o;
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < rows * C4; o += 256) {
+    const int tt = o / C4, c4 = o - tt * C4, c0 = 4 * c4;
+    float tap[28];
+    if (colfix) {
+#pragma unroll
+      for (int q = 0; q < 28; ++q) tap[q] = tapf[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const float4 tq = *reinterpret_cast<const float4*>(dw_w + (size_t)c0 * 7 + 4 * q);
+        tap[4 * q] = tq.x; tap[4 * q + 1] = tq.y; tap[4 * q + 2] = tq.z; tap[4 * q + 3] = tq.w;
+      }
+    }
+    float4 s = colfix ? dbf : *reinterpret_cast<const float4*>(dw_b + c0);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(xn + (size_t)(tt + k) * C + c0);
+      s.x = fmaf(tap[k], a.x, s.x); s.y = fmaf(tap[7 + k], a.y, s.y); s.z = fmaf(tap[14 + k], a.z, s.z); s.w = fmaf(tap[21 + k], a.w, s.w);
+    }
+    const float4 gm = colfix ? gmf : *reinterpret_cast<const float4*>(gamma + c0);
+    const float4 r = *reinterpret_cast<const float4*>(xraw + (size_t)tt * C + c0);
+    *reinterpret_cast<float4*>(out + (int64_t)(t0 + tt) * C + c0) = make_float4(r.x + gm.x * s.x, r.y + gm.y * s.y, r.z + gm.z * s.z, r.w + gm.w * s.w);
+  }
+  if (hist && blockIdx.x == 0) {
+    // new history = last 6 rows of [old history ; normalised x rows]: window row (src + 6) when this tile's window holds it
+    for (int j = wave; j < 6; j += 4) {
+      const int src = T - 6 + j;
+      float* dst = hist + (int64_t)j * C;
+      if (src < rows) {
+        for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(xn + (size_t)(src + 6) * C + c);
+      } else {
+        const float* xs = x + (int64_t)src * C;
+        float q = 0.f;
+        for (int c = lane * 4; c < C; c += 256) { const float4 a = *reinterpret_cast<const float4*>(xs + c); q += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+        const float rstd = rsqrtf(wave_sum_dpp(q) / (float)C + eps);
+        for (int c = lane * 4; c < C; c += 256) {
+          const float4 a = *reinterpret_cast<const float4*>(xs + c), nw = *reinterpret_cast<const float4*>(norm_w + c);
+          *reinterpret_cast<float4*>(dst + c) = make_float4(a.x * rstd * nw.x, a.y * rstd * nw.y, a.z * rstd * nw.z, a.w * rstd * nw.w);
+        }
+      }
+    }
+  }
+}
+
+int vv_mixer_init() {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(mixer_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+    return vv_set_error(VV_E_HIP, "vv_mixer_init: cannot raise the LDS limit");
+  return 0;
+}
+
+static int g_mixer_rows = 1;
+void vv_mixer_set_rows(int on) { g_mixer_rows = on; }
+
 extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const float* norm_w, float eps, const float* dw_w,
                               const float* dw_b, const float* gamma, float* hist, vv_stream_t stream) {
   if (!x || !out || !norm_w || !dw_w || !dw_b || !gamma) return vv_set_error(VV_E_ARG, "vv_block_mixer: null pointer");
   if (x == out) return vv_set_error(VV_E_ARG, "vv_block_mixer: in-place not allowed (halo rows)");
   if (T <= 0 || C <= 0) return vv_set_error(VV_E_ARG, "vv_block_mixer: bad shape");
+  {   // 16..256 rows x wide channels: one workgroup per 8 rows (mixer_rows_kernel); fewer rows keep the channel-sliced kernel
+      // (a single workgroup is slower than 32 slices: 13 vs 7 us at T = 1, C = 2048)
+    auto a16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    if (g_mixer_rows && T >= 16 && T <= 256 && C % 256 == 0 && C >= 256 && C <= 2048 && a16(x) && a16(out) && a16(norm_w) && a16(dw_w) && a16(dw_b) &&
+        a16(gamma) && (!hist || a16(hist))) {
+      int TRr = 8;
+      while (TRr > 1 && ((TRr + 6) * (C / 4) > 256 * MIXR_NI || TRr / 2 >= T)) TRr >>= 1;
+      if ((TRr + 6) * (C / 4) <= 256 * MIXR_NI && !(hist && T > TRr && TRr < 6)) {
+        const size_t ldsb = ((size_t)(TRr + 6) * C + (size_t)TRr * C + (size_t)(TRr + 6) * 8) * sizeof(float);
+        hipLaunchKernelGGL(mixer_rows_kernel, dim3((T + TRr - 1) / TRr), dim3(256), ldsb, (hipStream_t)stream, x, out, T, C, norm_w, eps,
+                           dw_w, dw_b, gamma, hist, TRr);
+        VV_CHECK_LAUNCH("vv_block_mixer");
+        return 0;
+      }
+    }
+  }
   int CS = 64;                                   // channel slice: power of two <= 64 that covers narrow stages exactly
   while (CS > 1 && CS / 2 >= C) CS >>= 1;
   int TR = T < MIX_TR ? T : MIX_TR;
