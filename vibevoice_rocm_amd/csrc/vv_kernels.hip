@@ -1231,14 +1231,31 @@ extern "C" int vv_block_mixer(const float* x, float* out, int T, int C, const fl
 }
 
 // pad[0:ctx] <- state; state <- last ctx rows of [state ; pad[ctx : ctx+T]]   (single block: ctx*C is tiny)
+// Row r of the new state is row T + r of the virtual sequence V = [state ; new rows]: an OLD state row while T + r < ctx, a new row
+// (pad[T + r], untouched by the prefix copy) otherwise - so every load of both copies is issued before the one barrier.
+#define CTX_NI 8
 __global__ __launch_bounds__(1024) void conv_ctx_kernel(float* pad, float* state, int ctx, int T, int C) {
   const int n = ctx * C;
-#pragma unroll 8
-  for (int i = threadIdx.x; i < n; i += blockDim.x) pad[i] = state[i];
-  __syncthreads();
-  // virtual sequence V = pad[0 : ctx+T]; new state = V[T : T+ctx]
-#pragma unroll 8
-  for (int i = threadIdx.x; i < n; i += blockDim.x) state[i] = pad[(int64_t)T * C + i];
+  float a[CTX_NI], b[CTX_NI];
+  const int tid = threadIdx.x;
+  for (int base = 0; base < n; base += 1024 * CTX_NI) {
+#pragma unroll
+    for (int u = 0; u < CTX_NI; ++u) {
+      const int i = base + tid + 1024 * u;
+      if (i < n) {
+        const int r = i / C;
+        a[u] = state[i];
+        b[u] = (T + r < ctx) ? state[(int64_t)T * C + i] : pad[(int64_t)T * C + i];
+      }
+    }
+    __syncthreads();                                   // all reads of the old state are done before it is rewritten
+#pragma unroll
+    for (int u = 0; u < CTX_NI; ++u) {
+      const int i = base + tid + 1024 * u;
+      if (i < n) { pad[i] = a[u]; state[i] = b[u]; }
+    }
+    __syncthreads();
+  }
 }
 
 extern "C" int vv_conv_ctx(float* pad, float* state, int ctx, int T, int C, vv_stream_t stream) {
