@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float tot = wave_sum(ss[u]);
+      const float tot = wave_sum_dpp(ss[u]);
       if (lane == 0 && rb + u < nrow) rstd_s[rb + u] = xr[u] ? rsqrtf(tot / (float)C + eps) : 1.f;   // history rows are stored normalised
     }
   }
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void block_mixer_kernel(const float* __restric
         const float* xs = x + (int64_t)src * C;
         float q = 0.f;
         for (int c = lane; c < C; c += 64) { const float v = xs[c]; q = fmaf(v, v, q); }
-        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        const float rstd = rsqrtf(wave_sum_dpp(q) / (float)C + eps);
         for (int c = lane; c < cs; c += 64) dst[c] = xs[c0 + c] * rstd * norm_w[c0 + c];
       }
     }
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(256) void cast_rows_bf16_kernel(const float* x, int
     float s = 0.f;
 #pragma unroll 4
     for (int c = tid; c < n; c += 256) { const float v = xr[c]; s = fmaf(v, v, s); }
-    s = wave_sum(s);
+    s = wave_sum_dpp(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
     rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* x, int64
   const float* xr = x + (int64_t)r * ldx;
   float s = 0.f;
   for (int c = tid; c < n; c += blockDim.x) s += xr[c] * xr[c];
-  s = wave_sum(s);
+  s = wave_sum_dpp(s);
   if (lane == 0) red[wave] = s;
   __syncthreads();
   const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
