@@ -101,9 +101,20 @@ __device__ __forceinline__ void epi4(const vv_lin_args& a, bool vec_ok, int m, i
   }
 }
 
+// phase timing of workgroup (0,0) / thread 0, debug builds only (-DVV_MFMA_TIMING, tools/mfma_phase_test.cpp)
+#ifdef VV_MFMA_TIMING
+__device__ unsigned long long g_mfma_t[8];
+#define MSTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); g_mfma_t[i] += (unsigned long long)(t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
+
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
 __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
   using T = Tile<MT>;
+#ifdef VV_MFMA_TIMING
+  long long tprev_ = wall_clock64();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                                             // [ROWS][PITCH]
   float* red = reinterpret_cast<float*>(smem);                                               // K-split combine scratch (aliases xs)
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
     }
   }
 
+  MSTAMP(0);                                         // row statistics
   f32x16 acc[MT], acc2[DUAL ? MT : 1];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       }
     }
     __syncthreads();
+    MSTAMP(1);                                       // staging (incl. the barrier before it)
     if (active) {
       const int nsteps = kc >> 4;
       int s_begin = 0, s_end = nsteps;
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
     }
   }
 
+  MSTAMP(2);                                         // weight loads + MFMA
   // ---- epilogue: D[n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][m = lane&31]: a lane holds 4 runs of 4 consecutive channels ----
   const bool vec_ok = (a.ldo % 4 == 0) && ((uintptr_t)a.out % 16 == 0) && (!a.res || (a.ldres % 4 == 0 && (uintptr_t)a.res % 16 == 0)) &&
                       (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.gate || ((uintptr_t)a.gate % 16 == 0 && a.gate_ld % 4 == 0));
@@ -295,6 +309,7 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
       }
     }
   }
+  MSTAMP(3);                                         // combine + epilogue
 }
 
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
@@ -353,6 +368,13 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   return rc ? rc : 1;
 }
 
+#ifdef VV_MFMA_TIMING
+extern "C" int vv_mfma_debug_times(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mfma_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
 void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; g_mt_prefill_xb = mt; }
 
