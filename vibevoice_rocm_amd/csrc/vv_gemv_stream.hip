@@ -5,6 +5,9 @@
 // for the whole kernel (prologue = RMSNorm / adaLN modulate / SiLU fused, computed once per wave), and the
 // workgroups are persistent: each wave walks its row groups with the next group's loads already in flight while
 // it reduces the current one (register double buffering), so the memory pipe never drains between rows.
+// Row sums use DPP row reductions (vv_wave_sum), every output's epilogue (bias / GELU / SwiGLU / gate / residual) runs in its own
+// lane on operands fetched one row group ahead, M <= 2 has an fp8 (e4m3fn codes + row scale) instantiation, M = 8 covers the
+// T = 8 conv stage when K splits to <= 2 units per wave.
 //   KSPLIT == 1        a wave owns RW whole weight rows per step (block = 4 independent waves)        K <= 2560
 //   KSPLIT == 4/8/16   the block's 4/8/16 waves split K (interleaved 512-element units) and combine through LDS
 //                      in a fixed order (long K: 1.5B down-projections, every 7B matrix)
@@ -37,15 +40,6 @@ __device__ __forceinline__ void unpack8_f8(const u32x4 v, float (&o)[8]) {
   const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
   const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
   o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y; o[6] = d.x; o[7] = d.y;
-}
-
-__device__ __forceinline__ void epi(const vv_lin_args& a, int m, int n, float v, float v2) {
-  if (a.bias) v += a.bias[n];
-  if (a.act == VV_ACT_GELU) v = gelu1(v);
-  else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
-  if (a.gate) v *= a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n];
-  if (a.res) v += a.res[(int64_t)m * a.ldres + n];
-  a.out[(int64_t)m * a.ldo + n] = v;
 }
 
 // epilogue operands (bias / adaLN gate / residual) of one output: their addresses are known before the dot product is, so
