@@ -66,6 +66,8 @@ __device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, floa
 }
 
 int g_blocks_override = 0;   // tuning hook (vv_tune)
+int g_long_cap = 512;        // persistent blocks for K-split launches with K > 6144 (tuning hook)
+int g_long_ku = 5;           // K units per wave allowed for rows longer than 12 units (tuning hook: 3 -> 8 waves split K)
 
 template <int M, bool DUAL, int KSPLIT, int KU, int RW, bool F8>
 __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
@@ -286,7 +288,7 @@ void launch_rw(const vv_lin_args& a, hipStream_t s) {
   const int work = (KSPLIT == 1) ? (n_groups + 3) / 4 : n_groups;       // blocks if each wave did exactly one group
   // K split: every block reads all of x (M x K fp32 from L2); beyond ~6K columns that traffic rivals the weights, so long
   // rows use fewer, persistent blocks (n=1536 k=8960: 10.4 us at 768 blocks, 9.1 us at 512)
-  const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : (a.k > 6144 ? 512 : 1024);
+  const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : (a.k > 6144 ? g_long_cap : 1024);
   int blocks = work < cap ? work : cap;
   if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
   if constexpr (M <= 2) {                        // fp8 weights: decode rows only
@@ -347,6 +349,7 @@ bool launch_m8(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
 }  // namespace
 
 void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
+void vv_gemv_stream_set_long(int cap, int ku) { if (cap > 0) g_long_cap = cap; if (ku > 0) g_long_ku = ku; }
 void vv_gemv_stream_set_dual_rw(int r) { g_dual_rw = r; }
 void vv_gemv_stream_set_small_rw(int r) { g_small_rw = r; }
 
@@ -379,7 +382,7 @@ int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s) {
   // dual kernel when K is split, its registers hold two weight streams)
   int ksplit = 1, ku = units;
   if (units > 5) {
-    const int kumax = dual ? 3 : 5;
+    const int kumax = dual ? 3 : (units > 12 ? g_long_ku : 5);
     ksplit = 0;
     for (int w : {4, 8, 16}) {
       if ((units + w - 1) / w <= kumax) { ksplit = w; ku = (units + w - 1) / w; break; }

@@ -38,12 +38,15 @@ extern "C" int vv_init(void) {
   return vv_chain_init();
 }
 void vv_gemv_stream_set_blocks(int b);
+void vv_gemv_stream_set_long(int cap, int ku);
 void vv_gemv_stream_set_dual_rw(int r);
 void vv_gemv_stream_set_small_rw(int r);
 void vv_mfma_set_mt(int mt);
 void vv_mixer_set_rows(int on);
 void vv_mfma_set_mt_prefill(int mt);
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
+  if (key && !strcmp(key, "gemv_long_cap")) { vv_gemv_stream_set_long(value, 0); return 0; }
+  if (key && !strcmp(key, "gemv_long_ku")) { vv_gemv_stream_set_long(0, value); return 0; }
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
