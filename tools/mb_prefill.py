@@ -25,6 +25,17 @@ for mt in (1, 2, 4):
     r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
     print("   first chunk", r["p50_ms"])
 voice = wl["speech_tensors"][0].cuda()
+for rows in (0, 1024, 4096):
+    lib.vv_tune(b"mfma_tiled_rows", rows)
+    for _ in range(2): eng.acoustic_encode(voice)
+    eng.stream.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): eng.acoustic_encode(voice)
+    eng.stream.synchronize()
+    print(f"mfma_tiled_rows={rows}: acoustic encode 27 s voice: {(time.perf_counter()-t0)/3*1e3:.2f} ms")
+    r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
+    print("   first chunk", r["p50_ms"])
+lib.vv_tune(b"mfma_tiled_rows", 1024)
 eng.stream.synchronize()
 t0 = time.perf_counter()
 for _ in range(3): eng.acoustic_encode(voice)

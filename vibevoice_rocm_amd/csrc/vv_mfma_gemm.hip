@@ -312,6 +312,99 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
   MSTAMP(3);                                         // combine + epilogue
 }
 
+// ---- tiled GEMM for LONG row counts (M >= 1024 rows of bf16 activations, N % 128 == 0, K % 32 == 0) ------------------------------
+// Whole-utterance voice-prompt encoding runs the conv FFNs over tens of thousands of rows: there the streaming kernel above
+// re-reads every activation strip once per 32-channel block.  Here a workgroup owns a 128 x 128 output tile: both operands go
+// global -> registers -> LDS in 128 x 32 slabs (double buffered, one barrier per K step), the 4 waves sit 2 x 2 and each holds
+// 2 x 2 MFMA 32x32 accumulators.  (Not used for the 330-row prompt prefill: with a few dozen tiles the one-slab-deep K loop is a
+// chain of L2 round trips and measured no faster than the streaming kernel.)
+constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 32, TG_PITCH = TG_BK + 8;
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
+  __shared__ __attribute__((aligned(16))) bf16_t xs[2][TG_BM * TG_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t wsm[2][TG_BN * TG_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t ws2[DUAL ? 2 : 1][DUAL ? TG_BN * TG_PITCH : 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.m, K = a.k;
+  const int n0 = blockIdx.x * TG_BN, m0 = blockIdx.y * TG_BM;
+  const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(a.x);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
+  const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
+  const int lr0 = tid >> 2, lr1 = lr0 + 64, lk = (tid & 3) * 8;       // a 128 x 32 slab = 512 16-byte pieces, two per thread
+  const bf16_t* xg0 = X + (int64_t)min(m0 + lr0, M - 1) * a.ldx + lk;
+  const bf16_t* xg1 = X + (int64_t)min(m0 + lr1, M - 1) * a.ldx + lk;
+  const bf16_t* wg0 = W + (int64_t)(n0 + lr0) * K + lk;
+  const bf16_t* wg1 = W + (int64_t)(n0 + lr1) * K + lk;
+  const bf16_t* vg0 = DUAL ? W2 + (int64_t)(n0 + lr0) * K + lk : nullptr;
+  const bf16_t* vg1 = DUAL ? W2 + (int64_t)(n0 + lr1) * K + lk : nullptr;
+  u32x4 rx0, rx1, rw0, rw1, rv0, rv1;
+  auto gload = [&](int k0) {
+    rx0 = *reinterpret_cast<const u32x4*>(xg0 + k0); rx1 = *reinterpret_cast<const u32x4*>(xg1 + k0);
+    rw0 = *reinterpret_cast<const u32x4*>(wg0 + k0); rw1 = *reinterpret_cast<const u32x4*>(wg1 + k0);
+    if (DUAL) { rv0 = *reinterpret_cast<const u32x4*>(vg0 + k0); rv1 = *reinterpret_cast<const u32x4*>(vg1 + k0); }
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<u32x4*>(&xs[buf][lr0 * TG_PITCH + lk]) = rx0; *reinterpret_cast<u32x4*>(&xs[buf][lr1 * TG_PITCH + lk]) = rx1;
+    *reinterpret_cast<u32x4*>(&wsm[buf][lr0 * TG_PITCH + lk]) = rw0; *reinterpret_cast<u32x4*>(&wsm[buf][lr1 * TG_PITCH + lk]) = rw1;
+    if (DUAL) { *reinterpret_cast<u32x4*>(&ws2[buf][lr0 * TG_PITCH + lk]) = rv0; *reinterpret_cast<u32x4*>(&ws2[buf][lr1 * TG_PITCH + lk]) = rv1; }
+  };
+  const int wn = wave & 1, wm = wave >> 1;
+  const int fr = lane & 31, fk = (lane >> 5) * 8;
+  f32x16 acc[2][2], acc2[DUAL ? 2 : 1][DUAL ? 2 : 1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (DUAL) acc2[i][j][r] = 0.f; }
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int nk = K / TG_BK;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) gload((ks + 1) * TG_BK);                        // next slab in flight while this one is multiplied
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      u32x4 fa[2], fb[2], fa2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(&wsm[buf][(wn * 64 + i * 32 + fr) * TG_PITCH + sub * 16 + fk]);
+        if (DUAL) fa2[i] = *reinterpret_cast<const u32x4*>(&ws2[buf][(wn * 64 + i * 32 + fr) * TG_PITCH + sub * 16 + fk]);
+        fb[i] = *reinterpret_cast<const u32x4*>(&xs[buf][(wm * 64 + i * 32 + fr) * TG_PITCH + sub * 16 + fk]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          if (DUAL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa2[i]), __builtin_bit_cast(bf16x8, fb[j]), acc2[i][j], 0, 0, 0);
+        }
+    }
+    if (ks + 1 < nk) lstore(buf ^ 1);                                // the other buffer was last read before the previous barrier
+    __syncthreads();
+  }
+  const bool vec_ok = (a.ldo % 4 == 0) && ((uintptr_t)a.out % 16 == 0) && (!a.res || (a.ldres % 4 == 0 && (uintptr_t)a.res % 16 == 0)) &&
+                      (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.gate || ((uintptr_t)a.gate % 16 == 0 && a.gate_ld % 4 == 0));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+      if (m >= M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        float v2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (DUAL) { v2[0] = acc2[i][j][4 * g]; v2[1] = acc2[i][j][4 * g + 1]; v2[2] = acc2[i][j][4 * g + 2]; v2[3] = acc2[i][j][4 * g + 3]; }
+        epi4(a, vec_ok, m, n0 + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5), v, v2);
+      }
+    }
+}
+
+int g_tiled_rows = 1024;   // rows from which the tiled kernel takes over (tuning hook "mfma_tiled_rows"; 0 = never)
+
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
 int launch(const vv_lin_args& a, hipStream_t s) {
   static bool attr_done = false;
@@ -345,6 +438,12 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (xb && a.pro != VV_PRO_NONE) return vv_set_error(VV_E_ARG, "vv_linear: a bf16 x takes no prologue");
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if ((a.k * 2) % 16) return 0;
+  if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && a.n % TG_BN == 0 && a.k % TG_BK == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
+    dim3 grid(a.n / TG_BN, (a.m + TG_BM - 1) / TG_BM);
+    if (a.w2) hipLaunchKernelGGL((mfma_tiled_kernel<true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mfma_tiled_kernel<false>), grid, dim3(256), 0, s, a);
+    return 1;
+  }
   // rows per workgroup.  MT > 1 (each weight fragment reused by MT 32-row tiles) was measured SLOWER on every shape of this
   // path on MI355X (19.8 vs 23.4 audio-s/s, first chunk 55 vs 51 ms): these GEMMs are latency bound, and fewer / fatter
   // workgroups with shorter LDS-resident K chunks cost more than the saved weight re-reads (which hit L2 / Infinity Cache).
@@ -376,6 +475,7 @@ extern "C" int vv_mfma_debug_times(unsigned long long* out8, int reset) {
 }
 #endif
 void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
+void vv_mfma_set_tiled_rows(int r) { g_tiled_rows = r; }
 void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; g_mt_prefill_xb = mt; }
 
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
