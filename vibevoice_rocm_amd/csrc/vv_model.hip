@@ -302,8 +302,18 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     // T > 8 rows on bf16 weights: both FFN linears run on the matrix cores and the 4C-wide hidden activation is handed
     // over in bf16 (half the bytes, and the second GEMM reads its fragments straight from it: no LDS staging)
     const bool handoff = net->wdt == VV_BF16 && T > 8 && C % 16 == 0 && ((uintptr_t)B.w1 % 16 == 0) && ((uintptr_t)B.w2 % 16 == 0);
-    vv_lin_args a = lin_base(other, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
-    a.pro = VV_PRO_RMSNORM; a.norm_w = B.ffn_norm_w; a.eps = net->eps; a.bias = B.b1; a.act = VV_ACT_GELU;
+    vv_lin_args a;
+    if (handoff && T >= 1024 && C % 32 == 0) {
+      // whole-utterance sequences: RMSNorm + bf16 cast once, then both FFN GEMMs stream bf16 activations (LDS-tiled 128 x 128
+      // kernel).  The cast rows live in the half of `hid` that the bf16 hidden tile leaves free.
+      void* xb = reinterpret_cast<char*>(hid) + (size_t)T * 4 * C * 2;
+      VV_TRY(vv_cast_rows_bf16(other, C, (int)T, C, VV_PRO_RMSNORM, B.ffn_norm_w, net->eps, xb, C, stream));
+      a = lin_base((const float*)xb, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
+      a.flags = VV_LIN_X_BF16; a.bias = B.b1; a.act = VV_ACT_GELU;
+    } else {
+      a = lin_base(other, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
+      a.pro = VV_PRO_RMSNORM; a.norm_w = B.ffn_norm_w; a.eps = net->eps; a.bias = B.b1; a.act = VV_ACT_GELU;
+    }
     if (handoff) a.flags |= VV_LIN_OUT_BF16;
     use_w8(a, B.q_w1);
     VV_TRY(vv_linear(&a, stream));
