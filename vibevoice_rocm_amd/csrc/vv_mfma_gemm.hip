@@ -322,6 +322,7 @@ constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 32, TG_PITCH = TG_BK + 8;
 
 template <bool DUAL>
 __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
+  constexpr int TG_D = DUAL ? 4 : 8;               // slabs in flight (registers: 16 / 24 per slab)
   __shared__ __attribute__((aligned(16))) bf16_t xs[2][TG_BM * TG_PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t wsm[2][TG_BN * TG_PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t ws2[DUAL ? 2 : 1][DUAL ? TG_BN * TG_PITCH : 8];
@@ -338,16 +339,19 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
   const bf16_t* wg1 = W + (int64_t)(n0 + lr1) * K + lk;
   const bf16_t* vg0 = DUAL ? W2 + (int64_t)(n0 + lr0) * K + lk : nullptr;
   const bf16_t* vg1 = DUAL ? W2 + (int64_t)(n0 + lr1) * K + lk : nullptr;
-  u32x4 rx0, rx1, rw0, rw1, rv0, rv1;
-  auto gload = [&](int k0) {
-    rx0 = *reinterpret_cast<const u32x4*>(xg0 + k0); rx1 = *reinterpret_cast<const u32x4*>(xg1 + k0);
-    rw0 = *reinterpret_cast<const u32x4*>(wg0 + k0); rw1 = *reinterpret_cast<const u32x4*>(wg1 + k0);
-    if (DUAL) { rv0 = *reinterpret_cast<const u32x4*>(vg0 + k0); rv1 = *reinterpret_cast<const u32x4*>(vg1 + k0); }
+  // global -> registers runs TG_D slabs ahead of the multiply (registers R[s % TG_D] hold slab s), registers -> LDS one slab
+  // ahead (double buffer): with few tiles per launch (a 330-row prefill) every K step would otherwise expose a full L2 round trip
+  struct Slab { u32x4 x0, x1, w0, w1, v0, v1; };
+  Slab R[TG_D];
+  auto gload = [&](Slab& r, int k0) {
+    r.x0 = *reinterpret_cast<const u32x4*>(xg0 + k0); r.x1 = *reinterpret_cast<const u32x4*>(xg1 + k0);
+    r.w0 = *reinterpret_cast<const u32x4*>(wg0 + k0); r.w1 = *reinterpret_cast<const u32x4*>(wg1 + k0);
+    if (DUAL) { r.v0 = *reinterpret_cast<const u32x4*>(vg0 + k0); r.v1 = *reinterpret_cast<const u32x4*>(vg1 + k0); }
   };
-  auto lstore = [&](int buf) {
-    *reinterpret_cast<u32x4*>(&xs[buf][lr0 * TG_PITCH + lk]) = rx0; *reinterpret_cast<u32x4*>(&xs[buf][lr1 * TG_PITCH + lk]) = rx1;
-    *reinterpret_cast<u32x4*>(&wsm[buf][lr0 * TG_PITCH + lk]) = rw0; *reinterpret_cast<u32x4*>(&wsm[buf][lr1 * TG_PITCH + lk]) = rw1;
-    if (DUAL) { *reinterpret_cast<u32x4*>(&ws2[buf][lr0 * TG_PITCH + lk]) = rv0; *reinterpret_cast<u32x4*>(&ws2[buf][lr1 * TG_PITCH + lk]) = rv1; }
+  auto lstore = [&](const Slab& r, int buf) {
+    *reinterpret_cast<u32x4*>(&xs[buf][lr0 * TG_PITCH + lk]) = r.x0; *reinterpret_cast<u32x4*>(&xs[buf][lr1 * TG_PITCH + lk]) = r.x1;
+    *reinterpret_cast<u32x4*>(&wsm[buf][lr0 * TG_PITCH + lk]) = r.w0; *reinterpret_cast<u32x4*>(&wsm[buf][lr1 * TG_PITCH + lk]) = r.w1;
+    if (DUAL) { *reinterpret_cast<u32x4*>(&ws2[buf][lr0 * TG_PITCH + lk]) = r.v0; *reinterpret_cast<u32x4*>(&ws2[buf][lr1 * TG_PITCH + lk]) = r.v1; }
   };
   const int wn = wave & 1, wm = wave >> 1;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
@@ -358,13 +362,12 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (DUAL) acc2[i][j][r] = 0.f; }
-  gload(0);
-  lstore(0);
-  __syncthreads();
   const int nk = K / TG_BK;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) gload((ks + 1) * TG_BK);                        // next slab in flight while this one is multiplied
+#pragma unroll
+  for (int d = 0; d < TG_D; ++d) if (d < nk) gload(R[d], d * TG_BK);
+  lstore(R[0], 0);
+  __syncthreads();
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       u32x4 fa[2], fb[2], fa2[2];
@@ -382,8 +385,18 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
           if (DUAL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa2[i]), __builtin_bit_cast(bf16x8, fb[j]), acc2[i][j], 0, 0, 0);
         }
     }
-    if (ks + 1 < nk) lstore(buf ^ 1);                                // the other buffer was last read before the previous barrier
-    __syncthreads();
+  };
+  for (int ks = 0; ks < nk; ks += TG_D) {                            // unrolled by TG_D: slab registers have fixed roles
+#pragma unroll
+    for (int j = 0; j < TG_D; ++j) {
+      const int it = ks + j;
+      if (it < nk) {
+        multiply(it & 1);
+        if (it + 1 < nk) lstore(R[(j + 1) % TG_D], (it & 1) ^ 1);    // slab it+1: requested TG_D-1 steps ago
+        if (it + TG_D < nk) gload(R[j], (it + TG_D) * TG_BK);        // R[j] held slab `it`, stored to LDS one step ago
+        __syncthreads();
+      }
+    }
   }
   const bool vec_ok = (a.ldo % 4 == 0) && ((uintptr_t)a.out % 16 == 0) && (!a.res || (a.ldres % 4 == 0 && (uintptr_t)a.res % 16 == 0)) &&
                       (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.gate || ((uintptr_t)a.gate % 16 == 0 && a.gate_ld % 4 == 0));
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
     }
 }
 
-int g_tiled_rows = 1024;   // rows from which the tiled kernel takes over (tuning hook "mfma_tiled_rows"; 0 = never)
+int g_tiled_rows = 128;    // rows from which the tiled kernel takes over (tuning hook "mfma_tiled_rows"; 0 = never)
 
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
 int launch(const vv_lin_args& a, hipStream_t s) {
