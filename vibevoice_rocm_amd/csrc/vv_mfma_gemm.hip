@@ -318,40 +318,54 @@ __global__ __launch_bounds__(256) void mfma_linear_kernel(const vv_lin_args a) {
 // global -> registers -> LDS in 128 x 32 slabs (double buffered, one barrier per K step), the 4 waves sit 2 x 2 and each holds
 // 2 x 2 MFMA 32x32 accumulators.  (Not used for the 330-row prompt prefill: with a few dozen tiles the one-slab-deep K loop is a
 // chain of L2 round trips and measured no faster than the streaming kernel.)
-constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 32, TG_PITCH = TG_BK + 8;
+constexpr int TG_BM = 128, TG_BN = 128;
 
-template <bool DUAL>
+// BK = 32 (dual / short K) or 128 (long K: a down-projection over K = 8960 is 70 barrier rounds instead of 280; each round is
+// dominated by the barrier + LDS hand-off, not by its 8 MFMAs)
+template <bool DUAL, int BK>
 __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
-  constexpr int TG_D = DUAL ? 4 : 8;               // slabs in flight (registers: 16 / 24 per slab)
-  __shared__ __attribute__((aligned(16))) bf16_t xs[2][TG_BM * TG_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t wsm[2][TG_BN * TG_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t ws2[DUAL ? 2 : 1][DUAL ? TG_BN * TG_PITCH : 8];
+  constexpr int PITCH = BK + 8;                    // bf16 pitch: the 32 rows of a fragment read hit distinct bank groups
+  constexpr int NP = BK / 16;                      // 16-byte pieces per thread per operand slab (128 rows x BK)
+  constexpr int PPR = BK / 8;                      // pieces per row
+  constexpr int TG_D = (BK == 32) ? (DUAL ? 4 : 8) : 2;   // slabs in flight in registers
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(tsm);                       // [2][128 * PITCH]
+  bf16_t* wsm = xs + 2 * TG_BM * PITCH;                              // [2][128 * PITCH]
+  bf16_t* ws2 = wsm + 2 * TG_BN * PITCH;                             // [2][128 * PITCH] (dual only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.m, K = a.k;
   const int n0 = blockIdx.x * TG_BN, m0 = blockIdx.y * TG_BM;
   const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(a.x);
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
   const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
-  const int lr0 = tid >> 2, lr1 = lr0 + 64, lk = (tid & 3) * 8;       // a 128 x 32 slab = 512 16-byte pieces, two per thread
-  const bf16_t* xg0 = X + (int64_t)min(m0 + lr0, M - 1) * a.ldx + lk;
-  const bf16_t* xg1 = X + (int64_t)min(m0 + lr1, M - 1) * a.ldx + lk;
-  const bf16_t* wg0 = W + (int64_t)(n0 + lr0) * K + lk;
-  const bf16_t* wg1 = W + (int64_t)(n0 + lr1) * K + lk;
-  const bf16_t* vg0 = DUAL ? W2 + (int64_t)(n0 + lr0) * K + lk : nullptr;
-  const bf16_t* vg1 = DUAL ? W2 + (int64_t)(n0 + lr1) * K + lk : nullptr;
-  // global -> registers runs TG_D slabs ahead of the multiply (registers R[s % TG_D] hold slab s), registers -> LDS one slab
-  // ahead (double buffer): with few tiles per launch (a 330-row prefill) every K step would otherwise expose a full L2 round trip
-  struct Slab { u32x4 x0, x1, w0, w1, v0, v1; };
+  // piece p = tid + 256 i of a slab: row p / PPR, k offset (p % PPR) * 8
+  int prow[NP], pk[NP];
+  const bf16_t* xg[NP]; const bf16_t* wg[NP]; const bf16_t* vg[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = tid + 256 * i;
+    prow[i] = p / PPR; pk[i] = (p % PPR) * 8;
+    xg[i] = X + (int64_t)min(m0 + prow[i], M - 1) * a.ldx + pk[i];
+    wg[i] = W + (int64_t)(n0 + prow[i]) * K + pk[i];
+    vg[i] = DUAL ? W2 + (int64_t)(n0 + prow[i]) * K + pk[i] : nullptr;
+  }
+  struct Slab { u32x4 x[NP], w[NP], v[DUAL ? NP : 1]; };
   Slab R[TG_D];
   auto gload = [&](Slab& r, int k0) {
-    r.x0 = *reinterpret_cast<const u32x4*>(xg0 + k0); r.x1 = *reinterpret_cast<const u32x4*>(xg1 + k0);
-    r.w0 = *reinterpret_cast<const u32x4*>(wg0 + k0); r.w1 = *reinterpret_cast<const u32x4*>(wg1 + k0);
-    if (DUAL) { r.v0 = *reinterpret_cast<const u32x4*>(vg0 + k0); r.v1 = *reinterpret_cast<const u32x4*>(vg1 + k0); }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      r.x[i] = *reinterpret_cast<const u32x4*>(xg[i] + k0);
+      r.w[i] = *reinterpret_cast<const u32x4*>(wg[i] + k0);
+      if (DUAL) r.v[i] = *reinterpret_cast<const u32x4*>(vg[i] + k0);
+    }
   };
   auto lstore = [&](const Slab& r, int buf) {
-    *reinterpret_cast<u32x4*>(&xs[buf][lr0 * TG_PITCH + lk]) = r.x0; *reinterpret_cast<u32x4*>(&xs[buf][lr1 * TG_PITCH + lk]) = r.x1;
-    *reinterpret_cast<u32x4*>(&wsm[buf][lr0 * TG_PITCH + lk]) = r.w0; *reinterpret_cast<u32x4*>(&wsm[buf][lr1 * TG_PITCH + lk]) = r.w1;
-    if (DUAL) { *reinterpret_cast<u32x4*>(&ws2[buf][lr0 * TG_PITCH + lk]) = r.v0; *reinterpret_cast<u32x4*>(&ws2[buf][lr1 * TG_PITCH + lk]) = r.v1; }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      *reinterpret_cast<u32x4*>(xs + buf * TG_BM * PITCH + prow[i] * PITCH + pk[i]) = r.x[i];
+      *reinterpret_cast<u32x4*>(wsm + buf * TG_BN * PITCH + prow[i] * PITCH + pk[i]) = r.w[i];
+      if (DUAL) *reinterpret_cast<u32x4*>(ws2 + buf * TG_BN * PITCH + prow[i] * PITCH + pk[i]) = r.v[i];
+    }
   };
   const int wn = wave & 1, wm = wave >> 1;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
@@ -362,20 +376,20 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (DUAL) acc2[i][j][r] = 0.f; }
-  const int nk = K / TG_BK;
+  const int nk = K / BK;
 #pragma unroll
-  for (int d = 0; d < TG_D; ++d) if (d < nk) gload(R[d], d * TG_BK);
+  for (int d = 0; d < TG_D; ++d) if (d < nk) gload(R[d], d * BK);
   lstore(R[0], 0);
   __syncthreads();
   auto multiply = [&](int buf) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < BK / 16; ++sub) {
       u32x4 fa[2], fb[2], fa2[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const u32x4*>(&wsm[buf][(wn * 64 + i * 32 + fr) * TG_PITCH + sub * 16 + fk]);
-        if (DUAL) fa2[i] = *reinterpret_cast<const u32x4*>(&ws2[buf][(wn * 64 + i * 32 + fr) * TG_PITCH + sub * 16 + fk]);
-        fb[i] = *reinterpret_cast<const u32x4*>(&xs[buf][(wm * 64 + i * 32 + fr) * TG_PITCH + sub * 16 + fk]);
+        fa[i] = *reinterpret_cast<const u32x4*>(wsm + buf * TG_BN * PITCH + (wn * 64 + i * 32 + fr) * PITCH + sub * 16 + fk);
+        if (DUAL) fa2[i] = *reinterpret_cast<const u32x4*>(ws2 + buf * TG_BN * PITCH + (wn * 64 + i * 32 + fr) * PITCH + sub * 16 + fk);
+        fb[i] = *reinterpret_cast<const u32x4*>(xs + buf * TG_BM * PITCH + (wm * 64 + i * 32 + fr) * PITCH + sub * 16 + fk);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
       if (it < nk) {
         multiply(it & 1);
         if (it + 1 < nk) lstore(R[(j + 1) % TG_D], (it & 1) ^ 1);    // slab it+1: requested TG_D-1 steps ago
-        if (it + TG_D < nk) gload(R[j], (it + TG_D) * TG_BK);        // R[j] held slab `it`, stored to LDS one step ago
+        if (it + TG_D < nk) gload(R[j], (it + TG_D) * BK);           // R[j] held slab `it`, stored to LDS one step ago
         __syncthreads();
       }
     }
@@ -416,6 +430,10 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
     }
 }
 
+template <bool DUAL, int BK>
+constexpr size_t tiled_lds() { return (size_t)(DUAL ? 3 : 2) * 2 * 128 * (BK + 8) * 2; }
+
+int g_tiled_bk128 = 1;     // long-K slabs for the non-dual tiled kernel (tuning hook "mfma_tiled_bk128")
 int g_tiled_rows = 128;    // rows from which the tiled kernel takes over (tuning hook "mfma_tiled_rows"; 0 = never)
 
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
@@ -451,10 +469,12 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (xb && a.pro != VV_PRO_NONE) return vv_set_error(VV_E_ARG, "vv_linear: a bf16 x takes no prologue");
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if ((a.k * 2) % 16) return 0;
-  if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && a.n % TG_BN == 0 && a.k % TG_BK == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
+  if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && a.n % TG_BN == 0 && a.k % 32 == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
     dim3 grid(a.n / TG_BN, (a.m + TG_BM - 1) / TG_BM);
-    if (a.w2) hipLaunchKernelGGL((mfma_tiled_kernel<true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mfma_tiled_kernel<false>), grid, dim3(256), 0, s, a);
+    const size_t lds_d = tiled_lds<true, 32>(), lds_l = tiled_lds<false, 128>(), lds_s = tiled_lds<false, 32>();
+    if (a.w2) hipLaunchKernelGGL((mfma_tiled_kernel<true, 32>), grid, dim3(256), lds_d, s, a);
+    else if (a.k % 128 == 0 && g_tiled_bk128) hipLaunchKernelGGL((mfma_tiled_kernel<false, 128>), grid, dim3(256), lds_l, s, a);
+    else hipLaunchKernelGGL((mfma_tiled_kernel<false, 32>), grid, dim3(256), lds_s, s, a);
     return 1;
   }
   // rows per workgroup.  MT > 1 (each weight fragment reused by MT 32-row tiles) was measured SLOWER on every shape of this
@@ -489,11 +509,17 @@ extern "C" int vv_mfma_debug_times(unsigned long long* out8, int reset) {
 #endif
 void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
 void vv_mfma_set_tiled_rows(int r) { g_tiled_rows = r; }
+void vv_mfma_set_tiled_bk128(int on) { g_tiled_bk128 = on; }
 void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; g_mt_prefill_xb = mt; }
 
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
 int vv_mfma_gemm_init() {
   hipError_t e;
+  const int lds_d = (int)tiled_lds<true, 32>(), lds_l = (int)tiled_lds<false, 128>(), lds_s = (int)tiled_lds<false, 32>();
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_l) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_d) != hipSuccess)
+    return vv_set_error(VV_E_HIP, "mfma init: cannot raise the LDS limit of the tiled kernel");
 #define VV_ATTR1(D, S, X, MTV)                                                                                           \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, X, MTV>),                              \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tile<MTV>::LDS);                               \
