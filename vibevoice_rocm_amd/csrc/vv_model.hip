@@ -70,6 +70,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   VV_TRY(vv_rope_table(lens, m->inv_freq, R, d, rope, stream));
   const bool prefill = (R >= VV_PREFILL_ROWS) && m->wdt == VV_BF16 && H % 16 == 0 && m->inter % 16 == 0 && qd % 16 == 0;
   void* xb = prefill ? (void*)c.take((size_t)R * (m->inter > H ? m->inter : H) / 2 + 64) : nullptr;
+  void* xb2 = prefill ? (void*)act : nullptr;      // bf16 SwiGLU output [R, inter] lives in the (otherwise unused) fp32 act buffer
   for (int l = 0; l < m->layers; ++l) {
     const vv_llm_layer& L = m->layer[l];
     vv_lin_args a;
@@ -109,10 +110,12 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     }
     a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
     if (!prefill) use_w8(a, L.q_gate, &L.q_up);
+    if (prefill) {            // the SwiGLU output is handed to the down projection in bf16: no separate cast pass
+      a.out = reinterpret_cast<float*>(xb2); a.ldo = m->inter; a.flags |= VV_LIN_OUT_BF16;
+    }
     VV_TRY(vv_linear(&a, stream));
     if (prefill) {
-      VV_TRY(vv_cast_rows_bf16(act, m->inter, R, m->inter, VV_PRO_NONE, nullptr, 0.f, xb, m->inter, stream));
-      a = lin_base((const float*)xb, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
+      a = lin_base((const float*)xb2, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
       a.flags = VV_LIN_X_BF16;
     } else {
       a = lin_base(act, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
