@@ -208,6 +208,8 @@ typedef struct vv_dpm_coef { float alpha_s, sigma_s, cx, cd, rinv; int order; fl
 
 /* out[(i*rows_b + j), :] = silu(a[j, :] + b[i, :]): the adaLN input silu(cond_proj(cond) + t_emb(t_i)) for all steps at once */
 int vv_add_rows_silu(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream);
+/* same, rounded to bf16 [rows, n] (the VV_LIN_X_BF16 operand of the hoisted adaLN GEMMs) */
+int vv_add_rows_silu_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, void* out, int rows, int rows_b, int n, vv_stream_t stream);
 /* step boundary of the sampler in one launch: x_out = DPM-Solver++/CFG update of (v, x_in, m_in) [v == NULL: x_out = x_in],
  * m_out = x0 prediction, and h[r, :] = W x_out for r < rows (the next step's noisy_images_proj; W == NULL: skipped).
  * x_in/x_out and m_in/m_out must be distinct buffers. */

@@ -13,7 +13,7 @@ wl = bench.build_workload(cfg, 225, 203)
 lib = L.load()
 eng = m.engine
 x0 = torch.randn(330, cfg.hidden, device="cuda")
-for mt, tr in ((4, 1024), (4, 128)):
+for mt, tr in ((4, 1024), (4, 32)):
     lib.vv_tune(b"mfma_mt_prefill", mt)
     lib.vv_tune(b"mfma_tiled_rows", tr)
     eng.begin_sequence(1024, [cfg.vocab-4, cfg.vocab-3, cfg.vocab-2, cfg.vocab-1])
@@ -26,7 +26,7 @@ for mt, tr in ((4, 1024), (4, 128)):
     r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
     print("   first chunk", r["p50_ms"])
 voice = wl["speech_tensors"][0].cuda()
-for rows in (1024, 128):
+for rows in (1024, 32):
     lib.vv_tune(b"mfma_tiled_rows", rows)
     for _ in range(2): eng.acoustic_encode(voice)
     eng.stream.synchronize()
@@ -36,7 +36,7 @@ for rows in (1024, 128):
     print(f"mfma_tiled_rows={rows}: acoustic encode 27 s voice: {(time.perf_counter()-t0)/3*1e3:.2f} ms")
     r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
     print("   first chunk", r["p50_ms"])
-lib.vv_tune(b"mfma_tiled_rows", 128)
+lib.vv_tune(b"mfma_tiled_rows", 32)
 eng.stream.synchronize()
 t0 = time.perf_counter()
 for _ in range(3): eng.acoustic_encode(voice)

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "vv_affine": (C.c_int, [vp, C.c_float, C.c_float, vp, i64, vp]),
     "vv_add_rows": (C.c_int, [vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
     "vv_add_rows_silu": (C.c_int, [vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "vv_add_rows_silu_bf16": (C.c_int, [vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),
     "vv_dpm_proj": (C.c_int, [vp, i64, C.c_float, C.POINTER(DpmCoef), vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp, vp]),
     "vv_embed_row": (C.c_int, [vp, C.c_int, i64, vp, vp, vp]),
     "vv_gather_rows": (C.c_int, [vp, C.c_int, i64, C.POINTER(C.c_int), C.c_int, vp, vp]),

@@ -1301,6 +1301,17 @@ extern "C" int vv_add_rows_silu(const float* a, int64_t lda, const float* b, int
   VV_CHECK_LAUNCH("vv_add_rows_silu");
   return 0;
 }
+// bf16 output: the operand of the hoisted adaLN GEMMs (rounded to bf16 by the matrix-core path anyway)
+__global__ void add_rows_silu_bf16_kernel(const float* a, int64_t lda, const float* b, int64_t ldb, bf16_t* out, int rows, int rows_b, int n) {
+  const int r = blockIdx.x, i = r / rows_b, j = r - i * rows_b;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) kv_store<bf16_t>(out + (int64_t)r * n + c, silu_f(a[(int64_t)j * lda + c] + b[(int64_t)i * ldb + c]));
+}
+extern "C" int vv_add_rows_silu_bf16(const float* a, int64_t lda, const float* b, int64_t ldb, void* out, int rows, int rows_b, int n, vv_stream_t stream) {
+  if (!a || !b || !out || rows <= 0 || rows_b <= 0 || rows % rows_b || n <= 0) return vv_set_error(VV_E_ARG, "vv_add_rows_silu_bf16: bad args");
+  hipLaunchKernelGGL(add_rows_silu_bf16_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, (bf16_t*)out, rows, rows_b, n);
+  VV_CHECK_LAUNCH("vv_add_rows_silu_bf16");
+  return 0;
+}
 extern "C" int vv_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int rows, int rows_b, int n, vv_stream_t stream) {
   if (!a || !b || !out || rows <= 0 || rows_b <= 0 || rows % rows_b || n <= 0) return vv_set_error(VV_E_ARG, "vv_add_rows: bad args");
   hipLaunchKernelGGL(add_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, rows, rows_b, n);

@@ -434,7 +434,7 @@ template <bool DUAL, int BK>
 constexpr size_t tiled_lds() { return (size_t)(DUAL ? 3 : 2) * 2 * 128 * (BK + 8) * 2; }
 
 int g_tiled_bk128 = 1;     // long-K slabs for the non-dual tiled kernel (tuning hook "mfma_tiled_bk128")
-int g_tiled_rows = 128;    // rows from which the tiled kernel takes over (tuning hook "mfma_tiled_rows"; 0 = never)
+int g_tiled_rows = 32;     // fewest rows for the tiled kernel (tuning hook "mfma_tiled_rows"; 0 = never); it also needs >= 24 tiles
 
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
 int launch(const vv_lin_args& a, hipStream_t s) {
@@ -469,7 +469,10 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (xb && a.pro != VV_PRO_NONE) return vv_set_error(VV_E_ARG, "vv_linear: a bf16 x takes no prologue");
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;
   if ((a.k * 2) % 16) return 0;
-  if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && a.n % TG_BN == 0 && a.k % 32 == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
+  // the tiled kernel needs enough 128 x 128 tiles to occupy the chip's memory system (prefill: 36-210, voice-prompt encode: hundreds,
+  // hoisted adaLN: 36); a conv-stage GEMM with 4 tiles stays on the streaming kernel (T = 200, C = 256: 8 us there, 25 us tiled)
+  const bool enough_tiles = (long)(a.n / TG_BN) * ((a.m + TG_BM - 1) / TG_BM) >= 24;
+  if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && enough_tiles && a.n % TG_BN == 0 && a.k % 32 == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
     dim3 grid(a.n / TG_BN, (a.m + TG_BM - 1) / TG_BM);
     const size_t lds_d = tiled_lds<true, 32>(), lds_l = tiled_lds<false, 128>(), lds_s = tiled_lds<false, 32>();
     if (a.w2) hipLaunchKernelGGL((mfma_tiled_kernel<true, 32>), grid, dim3(256), lds_d, s, a);

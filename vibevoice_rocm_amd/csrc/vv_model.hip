@@ -169,15 +169,19 @@ static int head_body(const vv_head* h, const float* x, int64_t ldx, int R, float
   return vv_linear(&a, stream);
 }
 
-static int head_modulations(const vv_head* h, const float* c, int rows, float* const* mod, float* modf, bool presilu, vv_stream_t stream) {
+// c: fp32 rows (presilu false: SiLU applied as the GEMM prologue) or, with c_bf16, SiLU'd rows already rounded to bf16 (the operand the
+// matrix-core path would round to anyway; the >= 32-tile adaLN GEMMs then run on the LDS-tiled kernel)
+static int head_modulations(const vv_head* h, const float* c, int rows, float* const* mod, float* modf, bool presilu, bool c_bf16, vv_stream_t stream) {
   const int D = h->D;
   for (int l = 0; l < h->layers; ++l) {
     vv_lin_args a = lin_base(c, D, rows, h->layer[l].adaln, 3 * D, D, h->wdt, mod[l], 3 * D);
     a.pro = presilu ? VV_PRO_NONE : VV_PRO_SILU;
+    if (c_bf16) a.flags = VV_LIN_X_BF16;
     VV_TRY(vv_linear(&a, stream));
   }
   vv_lin_args a = lin_base(c, D, rows, h->final_adaln, 2 * D, D, h->wdt, modf, 2 * D);
   a.pro = presilu ? VV_PRO_NONE : VV_PRO_SILU;
+  if (c_bf16) a.flags = VV_LIN_X_BF16;
   return vv_linear(&a, stream);
 }
 
@@ -198,7 +202,7 @@ extern "C" int vv_head_forward(const vv_head* h, const float* x, const float* te
   VV_TRY(vv_linear(&a, stream));
   // c[r] = c0[r] + temb_rows[r]: rows_b = R with a single "step" whose b-row is row r -> use add_rows twice-free form
   for (int r = 0; r < R; ++r) VV_TRY(vv_add_rows(c0 + (size_t)r * D, D, temb_rows + (size_t)r * D, D, c + (size_t)r * D, 1, 1, D, stream));
-  VV_TRY(head_modulations(h, c, R, mod, modf, false, stream));
+  VV_TRY(head_modulations(h, c, R, mod, modf, false, false, stream));
   return head_body(h, x, h->latent, R, mod, modf, 0, hcur, act, v, stream);
 }
 
@@ -225,8 +229,10 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   // step-invariant work hoisted out of the loop: cond_proj, silu(cond_proj(cond) + t_emb(t_i)), all adaLN modulations
   vv_lin_args a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
   VV_TRY(vv_linear(&a, stream));
-  VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
-  VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, stream));
+  const bool cb = h->wdt == VV_BF16 && 2 * n_steps > 8 && D % 32 == 0 && ((uintptr_t)c % 16 == 0);
+  if (cb) VV_TRY(vv_add_rows_silu_bf16(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+  else VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+  VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, cb, stream));
   // the whole solver loop as one persistent kernel (vv_chain.hip) when the shapes are covered
   const int chained = sde_noise ? 0 : vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
   if (chained < 0) return chained;
