@@ -156,19 +156,20 @@ def test_decoder_and_semantic_frames_1p5b_vs_oracle(big):
 
 
 def test_voice_prompt_encode_1p5b_vs_oracle(big):
-    """Whole-utterance (non-streaming, zero left padding) acoustic encoder at real shapes on a ragged length: 6 hops + 777 samples ->
-    7 latent frames; the narrow stages run as fused Block1D launches (T = 19977 / 9989 / 4995 rows, not multiples of 32), the
-    C = 256 stage (1249 rows) takes the >= 1024-row route: RMSNorm + bf16 cast, then both FFN GEMMs on the LDS-tiled kernel."""
+    """Whole-utterance (non-streaming, zero left padding) acoustic encoder at real shapes on a ragged length: 8 hops + 777 samples ->
+    9 latent frames; the narrow stages run as fused Block1D launches (T = 26377 / 13189 / 6595 rows, not multiples of 32), the
+    128 -> 256 strided conv (1649 output rows, 26 tiles) and the C = 256 / 512 stages take the long-sequence route: bf16 cast
+    (with RMSNorm for the FFN), then the LDS-tiled GEMM."""
     from oracle import vv_oracle as O
     cfg, sd, m = big
     eng = m.engine
     W = _cpu(sd, "model.acoustic_tokenizer.encoder.")
     g = torch.Generator().manual_seed(8)
-    wav = 0.1 * torch.randn(6 * cfg.hop + 777, generator=g)
+    wav = 0.1 * torch.randn(8 * cfg.hop + 777, generator=g)
     ref = O.acoustic_encode(W, cfg.as_dict(), wav[None])
     got = eng.acoustic_encode(wav)
     eng.stream.synchronize()
-    assert tuple(got.shape) == tuple(ref.shape) == (7, cfg.ac_dim)
+    assert tuple(got.shape) == tuple(ref.shape) == (9, cfg.ac_dim)
     assert rel_rms(got.cpu().numpy(), ref.numpy()) < 2e-2
 
 

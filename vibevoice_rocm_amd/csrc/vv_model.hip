@@ -312,9 +312,11 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     // over in bf16 (half the bytes, and the second GEMM reads its fragments straight from it: no LDS staging)
     const bool handoff = net->wdt == VV_BF16 && T > 8 && C % 16 == 0 && ((uintptr_t)B.w1 % 16 == 0) && ((uintptr_t)B.w2 % 16 == 0);
     vv_lin_args a;
-    if (handoff && T >= 1024 && C % 32 == 0) {
-      // whole-utterance sequences: RMSNorm + bf16 cast once, then both FFN GEMMs stream bf16 activations (LDS-tiled 128 x 128
-      // kernel).  The cast rows live in the half of `hid` that the bf16 hidden tile leaves free.
+    const long tiles1 = (long)((4 * C) / 128) * ((T + 127) / 128);   // 128 x 128 output tiles of the first FFN GEMM
+    if (handoff && C % 32 == 0 && (4 * C) % 128 == 0 && T >= 64 && tiles1 >= 24) {
+      // whole-utterance sequences (enough output tiles for the LDS-tiled 128 x 128 kernel; a streaming frame never has them):
+      // RMSNorm + bf16 cast once, then both FFN GEMMs stream bf16 activations.  The cast rows live in the half of `hid`
+      // that the bf16 hidden tile leaves free.
       void* xb = reinterpret_cast<char*>(hid) + (size_t)T * 4 * C * 2;
       VV_TRY(vv_cast_rows_bf16(other, C, (int)T, C, VV_PRO_RMSNORM, B.ffn_norm_w, net->eps, xb, C, stream));
       a = lin_base((const float*)xb, C, (int)T, B.w1, 4 * C, C, net->wdt, hid, 4 * C);
@@ -439,6 +441,16 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
     float* outb = is_head ? feat : ((pad == A) ? Bf : A);
     vv_lin_args a = lin_base(pad, (int64_t)cv.stride * cv.cin, (int)Tout, cv.w, cv.cout, cv.kk * cv.cin, net->wdt, outb, cv.cout);
     a.bias = cv.b;
+    {   // whole-utterance sequences: the padded input is cast to bf16 once (into `hid`, free between stages) and the conv - a GEMM
+        // over overlapping rows - runs on the LDS-tiled kernel; a streaming frame never has the >= 24 output tiles this needs
+      const long tiles = (long)(cv.cout / 128) * ((Tout + 127) / 128);
+      const size_t in_el = (size_t)need * cv.cin;
+      if (net->wdt == VV_BF16 && !is_head && cv.cout % 128 == 0 && (cv.kk * cv.cin) % 32 == 0 && (cv.stride * cv.cin) % 8 == 0 && cv.cin >= 128 && cv.cin % 8 == 0 &&
+          tiles >= 24 && in_el * 2 <= hel * 4 && ((uintptr_t)cv.w % 16 == 0)) {
+        VV_TRY(vv_cast_rows_bf16(pad, cv.cin, (int)need, cv.cin, VV_PRO_NONE, nullptr, 0.f, hid, cv.cin, stream));
+        a.x = hid; a.flags = VV_LIN_X_BF16;
+      }
+    }
     VV_TRY(vv_linear(&a, stream));
     if (is_head) break;
     T = Tout;
