@@ -13,32 +13,22 @@ wl = bench.build_workload(cfg, 225, 203)
 lib = L.load()
 eng = m.engine
 x0 = torch.randn(330, cfg.hidden, device="cuda")
-for mt, tr in ((4, 1024), (4, 32)):
-    lib.vv_tune(b"mfma_mt_prefill", mt)
-    lib.vv_tune(b"mfma_tiled_rows", tr)
+voice = wl["speech_tensors"][0].cuda()
+for small, sk in ((200, 0), (200, 256), (200, 1000), (200, 0), (200, 256)):
+    lib.vv_tune(b"mfma_tiled_small", small)
+    lib.vv_tune(b"mfma_tiled_small_dual", sk)
     eng.begin_sequence(1024, [cfg.vocab-4, cfg.vocab-3, cfg.vocab-2, cfg.vocab-1])
     for _ in range(2): eng.prefill(x0, row=0)
     eng.stream.synchronize()
     t0 = time.perf_counter()
     for _ in range(5): eng.prefill(x0, row=0)
     eng.stream.synchronize()
-    print(f"mt_prefill={mt} tiled_rows={tr}: LLM prefill 330 tokens {(time.perf_counter()-t0)/5*1e3:.2f} ms")
-    r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
-    print("   first chunk", r["p50_ms"])
-voice = wl["speech_tensors"][0].cuda()
-for rows in (1024, 32):
-    lib.vv_tune(b"mfma_tiled_rows", rows)
+    tp = (time.perf_counter()-t0)/5*1e3
     for _ in range(2): eng.acoustic_encode(voice)
     eng.stream.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): eng.acoustic_encode(voice)
     eng.stream.synchronize()
-    print(f"mfma_tiled_rows={rows}: acoustic encode 27 s voice: {(time.perf_counter()-t0)/3*1e3:.2f} ms")
+    tv = (time.perf_counter()-t0)/3*1e3
     r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
-    print("   first chunk", r["p50_ms"])
-lib.vv_tune(b"mfma_tiled_rows", 32)
-eng.stream.synchronize()
-t0 = time.perf_counter()
-for _ in range(3): eng.acoustic_encode(voice)
-eng.stream.synchronize()
-print(f"acoustic encode 27 s voice: {(time.perf_counter()-t0)/3*1e3:.2f} ms")
+    print(f"mfma_tiled_small={small} dual<{sk}: prefill {tp:.2f} ms, voice encode {tv:.2f} ms, first chunk {r['p50_ms']}")

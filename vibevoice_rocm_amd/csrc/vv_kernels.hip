@@ -44,6 +44,9 @@ void vv_gemv_stream_set_small_rw(int r);
 void vv_mfma_set_mt(int mt);
 void vv_mfma_set_tiled_rows(int r);
 void vv_mfma_set_tiled_bk128(int on);
+void vv_mfma_set_tiled_small(int t);
+void vv_mfma_set_tiled_small_dual(int t);
+void vv_mfma_set_tiled_small_k(int k);
 void vv_mixer_set_rows(int on);
 void vv_mfma_set_mt_prefill(int mt);
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
@@ -59,6 +62,9 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }
   if (key && !strcmp(key, "head_chain")) { vv_chain_set_head(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_bk128")) { vv_mfma_set_tiled_bk128(value); return 0; }
+  if (key && !strcmp(key, "mfma_tiled_small_k")) { vv_mfma_set_tiled_small_k(value); return 0; }
+  if (key && !strcmp(key, "mfma_tiled_small_dual")) { vv_mfma_set_tiled_small_dual(value); return 0; }
+  if (key && !strcmp(key, "mfma_tiled_small")) { vv_mfma_set_tiled_small(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_rows")) { vv_mfma_set_tiled_rows(value); return 0; }
   if (key && !strcmp(key, "mfma_mt")) { vv_mfma_set_mt(value); return 0; }
   if (key && !strcmp(key, "mfma_mt_prefill")) { vv_mfma_set_mt_prefill(value); return 0; }

@@ -322,19 +322,20 @@ constexpr int TG_BM = 128, TG_BN = 128;
 
 // BK = 32 (dual / short K) or 128 (long K: a down-projection over K = 8960 is 70 barrier rounds instead of 280; each round is
 // dominated by the barrier + LDS hand-off, not by its 8 MFMAs)
-template <bool DUAL, int BK>
+template <bool DUAL, int BK, int TM>
 __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
   constexpr int PITCH = BK + 8;                    // bf16 pitch: the 32 rows of a fragment read hit distinct bank groups
-  constexpr int NP = BK / 16;                      // 16-byte pieces per thread per operand slab (128 rows x BK)
+  constexpr int NP = TM * BK / (8 * 256);          // 16-byte pieces per thread per operand slab (TM rows x BK)
+  constexpr int FI = TM / 64;                      // 32 x 32 accumulators per wave per direction (waves sit 2 x 2)
   constexpr int PPR = BK / 8;                      // pieces per row
-  constexpr int TG_D = (BK == 32) ? (DUAL ? 4 : 8) : 2;   // slabs in flight in registers
+  constexpr int TG_D = (BK == 32) ? (DUAL ? 4 : 8) : (TM == 64 ? 4 : 2);   // slabs in flight in registers
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(tsm);                       // [2][128 * PITCH]
-  bf16_t* wsm = xs + 2 * TG_BM * PITCH;                              // [2][128 * PITCH]
-  bf16_t* ws2 = wsm + 2 * TG_BN * PITCH;                             // [2][128 * PITCH] (dual only)
+  bf16_t* wsm = xs + 2 * TM * PITCH;                              // [2][128 * PITCH]
+  bf16_t* ws2 = wsm + 2 * TM * PITCH;                             // [2][128 * PITCH] (dual only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.m, K = a.k;
-  const int n0 = blockIdx.x * TG_BN, m0 = blockIdx.y * TG_BM;
+  const int n0 = blockIdx.x * TM, m0 = blockIdx.y * TM;
   const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(a.x);
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
   const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
@@ -362,18 +363,18 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
   auto lstore = [&](const Slab& r, int buf) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      *reinterpret_cast<u32x4*>(xs + buf * TG_BM * PITCH + prow[i] * PITCH + pk[i]) = r.x[i];
-      *reinterpret_cast<u32x4*>(wsm + buf * TG_BN * PITCH + prow[i] * PITCH + pk[i]) = r.w[i];
-      if (DUAL) *reinterpret_cast<u32x4*>(ws2 + buf * TG_BN * PITCH + prow[i] * PITCH + pk[i]) = r.v[i];
+      *reinterpret_cast<u32x4*>(xs + buf * TM * PITCH + prow[i] * PITCH + pk[i]) = r.x[i];
+      *reinterpret_cast<u32x4*>(wsm + buf * TM * PITCH + prow[i] * PITCH + pk[i]) = r.w[i];
+      if (DUAL) *reinterpret_cast<u32x4*>(ws2 + buf * TM * PITCH + prow[i] * PITCH + pk[i]) = r.v[i];
     }
   };
   const int wn = wave & 1, wm = wave >> 1;
   const int fr = lane & 31, fk = (lane >> 5) * 8;
-  f32x16 acc[2][2], acc2[DUAL ? 2 : 1][DUAL ? 2 : 1];
+  f32x16 acc[FI][FI], acc2[DUAL ? FI : 1][DUAL ? FI : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (DUAL) acc2[i][j][r] = 0.f; }
   const int nk = K / BK;
@@ -384,17 +385,17 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
   auto multiply = [&](int buf) {
 #pragma unroll
     for (int sub = 0; sub < BK / 16; ++sub) {
-      u32x4 fa[2], fb[2], fa2[2];
+      u32x4 fa[FI], fb[FI], fa2[FI];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const u32x4*>(wsm + buf * TG_BN * PITCH + (wn * 64 + i * 32 + fr) * PITCH + sub * 16 + fk);
-        if (DUAL) fa2[i] = *reinterpret_cast<const u32x4*>(ws2 + buf * TG_BN * PITCH + (wn * 64 + i * 32 + fr) * PITCH + sub * 16 + fk);
-        fb[i] = *reinterpret_cast<const u32x4*>(xs + buf * TG_BM * PITCH + (wm * 64 + i * 32 + fr) * PITCH + sub * 16 + fk);
+      for (int i = 0; i < FI; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(wsm + buf * TM * PITCH + (wn * (TM / 2) + i * 32 + fr) * PITCH + sub * 16 + fk);
+        if (DUAL) fa2[i] = *reinterpret_cast<const u32x4*>(ws2 + buf * TM * PITCH + (wn * (TM / 2) + i * 32 + fr) * PITCH + sub * 16 + fk);
+        fb[i] = *reinterpret_cast<const u32x4*>(xs + buf * TM * PITCH + (wm * (TM / 2) + i * 32 + fr) * PITCH + sub * 16 + fk);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < FI; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
           if (DUAL) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa2[i]), __builtin_bit_cast(bf16x8, fb[j]), acc2[i][j], 0, 0, 0);
         }
@@ -415,25 +416,28 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
   const bool vec_ok = (a.ldo % 4 == 0) && ((uintptr_t)a.out % 16 == 0) && (!a.res || (a.ldres % 4 == 0 && (uintptr_t)a.res % 16 == 0)) &&
                       (!a.bias || (uintptr_t)a.bias % 16 == 0) && (!a.gate || ((uintptr_t)a.gate % 16 == 0 && a.gate_ld % 4 == 0));
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < FI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < FI; ++j) {
+      const int m = m0 + wm * (TM / 2) + j * 32 + (lane & 31);
       if (m >= M) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         float v2[4] = {0.f, 0.f, 0.f, 0.f};
         if (DUAL) { v2[0] = acc2[i][j][4 * g]; v2[1] = acc2[i][j][4 * g + 1]; v2[2] = acc2[i][j][4 * g + 2]; v2[3] = acc2[i][j][4 * g + 3]; }
-        epi4(a, vec_ok, m, n0 + wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5), v, v2);
+        epi4(a, vec_ok, m, n0 + wn * (TM / 2) + i * 32 + 8 * g + 4 * (lane >> 5), v, v2);
       }
     }
 }
 
-template <bool DUAL, int BK>
-constexpr size_t tiled_lds() { return (size_t)(DUAL ? 3 : 2) * 2 * 128 * (BK + 8) * 2; }
+template <bool DUAL, int BK, int TM = 128>
+constexpr size_t tiled_lds() { return (size_t)(DUAL ? 3 : 2) * 2 * TM * (BK + 8) * 2; }
 
 int g_tiled_bk128 = 1;     // long-K slabs for the non-dual tiled kernel (tuning hook "mfma_tiled_bk128")
+int g_tiled_small = 200;  // below this many 128 x 128 tiles a long-K GEMM uses 64 x 64 tiles (tuning hook "mfma_tiled_small"; 0 = never)
+int g_tiled_small_k = 1024;     // shortest K for the 64 x 64 variant (tuning hook "mfma_tiled_small_k")
+int g_tiled_small_dual = 256;   // same for the dual (SwiGLU gate/up) GEMM: prefill gate/up is 210 tiles (tuning hook "mfma_tiled_small_dual")
 int g_tiled_rows = 32;     // fewest rows for the tiled kernel (tuning hook "mfma_tiled_rows"; 0 = never); it also needs >= 24 tiles
 
 template <bool DUAL, bool KSPLIT, bool XB, int MT>
@@ -475,9 +479,23 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && enough_tiles && a.n % TG_BN == 0 && a.k % 32 == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
     dim3 grid(a.n / TG_BN, (a.m + TG_BM - 1) / TG_BM);
     const size_t lds_d = tiled_lds<true, 32>(), lds_l = tiled_lds<false, 128>(), lds_s = tiled_lds<false, 32>();
-    if (a.w2) hipLaunchKernelGGL((mfma_tiled_kernel<true, 32>), grid, dim3(256), lds_d, s, a);
-    else if (a.k % 128 == 0 && g_tiled_bk128) hipLaunchKernelGGL((mfma_tiled_kernel<false, 128>), grid, dim3(256), lds_l, s, a);
-    else hipLaunchKernelGGL((mfma_tiled_kernel<false, 32>), grid, dim3(256), lds_s, s, a);
+    const size_t lds_q = tiled_lds<false, 128, 64>(), lds_qd = tiled_lds<true, 32, 64>();
+    // a long-K GEMM on a few dozen 128 x 128 tiles (prefill down-projection: 36 tiles x 70 K rounds; the T = 200 stage of a voice-
+    // prompt encode: 32 tiles x 64 rounds) leaves most CUs idle behind a serial K loop: 64 x 64 tiles give 4x the workgroups,
+    // each with a quarter of the MFMA / LDS work per round and a 4-slab-deep register prefetch
+    if (a.w2 && (long)grid.x * grid.y < g_tiled_small_dual) {
+      dim3 gq(a.n / 64, (a.m + 63) / 64);
+      hipLaunchKernelGGL((mfma_tiled_kernel<true, 32, 64>), gq, dim3(256), lds_qd, s, a);
+      return 1;
+    }
+    if (!a.w2 && g_tiled_small > 0 && a.k % 128 == 0 && a.k >= g_tiled_small_k && (long)grid.x * grid.y < g_tiled_small) {
+      dim3 gq(a.n / 64, (a.m + 63) / 64);
+      hipLaunchKernelGGL((mfma_tiled_kernel<false, 128, 64>), gq, dim3(256), lds_q, s, a);
+      return 1;
+    }
+    if (a.w2) hipLaunchKernelGGL((mfma_tiled_kernel<true, 32, 128>), grid, dim3(256), lds_d, s, a);
+    else if (a.k % 128 == 0 && g_tiled_bk128) hipLaunchKernelGGL((mfma_tiled_kernel<false, 128, 128>), grid, dim3(256), lds_l, s, a);
+    else hipLaunchKernelGGL((mfma_tiled_kernel<false, 32, 128>), grid, dim3(256), lds_s, s, a);
     return 1;
   }
   // rows per workgroup.  MT > 1 (each weight fragment reused by MT 32-row tiles) was measured SLOWER on every shape of this
@@ -513,15 +531,21 @@ extern "C" int vv_mfma_debug_times(unsigned long long* out8, int reset) {
 void vv_mfma_set_mt(int mt) { g_mt_override = mt; }
 void vv_mfma_set_tiled_rows(int r) { g_tiled_rows = r; }
 void vv_mfma_set_tiled_bk128(int on) { g_tiled_bk128 = on; }
+void vv_mfma_set_tiled_small(int t) { g_tiled_small = t; }
+void vv_mfma_set_tiled_small_k(int k) { g_tiled_small_k = k; }
+void vv_mfma_set_tiled_small_dual(int t) { g_tiled_small_dual = t; }
 void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; g_mt_prefill_xb = mt; }
 
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
 int vv_mfma_gemm_init() {
   hipError_t e;
   const int lds_d = (int)tiled_lds<true, 32>(), lds_l = (int)tiled_lds<false, 128>(), lds_s = (int)tiled_lds<false, 32>();
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_l) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_d) != hipSuccess)
+  const int lds_q = (int)tiled_lds<false, 128, 64>(), lds_qd = (int)tiled_lds<true, 32, 64>();
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_qd) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_l) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_d) != hipSuccess)
     return vv_set_error(VV_E_HIP, "mfma init: cannot raise the LDS limit of the tiled kernel");
 #define VV_ATTR1(D, S, X, MTV)                                                                                           \
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_linear_kernel<D, S, X, MTV>),                              \
