@@ -650,3 +650,37 @@ def test_generate_mid_vs_oracle(mid, dtype, tol):
     got = out.speech_outputs[0][0].cpu().numpy()
     assert got.shape == ref_wav.shape == (9 * cfg.hop,)
     assert rel_rms(got, ref_wav) < tol
+
+
+@pytest.mark.parametrize("heads,kv_heads,d,kvdt,R,pos0", [(12, 2, 128, "bf16", 77, 0), (12, 2, 128, "f32", 21, 5), (28, 4, 128, "bf16", 40, 3),
+                                                        (4, 2, 16, "f32", 19, 0), (4, 2, 128, "bf16", 9, 130), (6, 2, 128, "bf16", 33, 0)])
+def test_prompt_attention_vs_torch(lib, heads, kv_heads, d, kvdt, R, pos0):
+    """vv_attn at prompt row counts (causal: row r sees keys 0..pos0+r of one cache row).  GQA ratios 6 / 7 / 2 take the kernel that
+    shares K/V loads across the q heads of a group, ratio 3 the per-head kernel; both against a softmax in torch fp32 on the same
+    cache contents (reference call site: Qwen2 attention under modeling_vibevoice_inference.py:226-237)."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(heads * 100 + R)
+    layers, rows, s_max, layer = 2, 2, pos0 + R + 3, 1
+    tdt = torch.bfloat16 if kvdt == "bf16" else torch.float32
+    kc = torch.randn(layers, rows, kv_heads, s_max, d, generator=g).to(tdt)
+    vc = torch.randn(layers, rows, kv_heads, s_max, d, generator=g).to(tdt)
+    ld = (heads + 2 * kv_heads) * d
+    qkv = torch.randn(R, ld, generator=g)
+    lens = torch.arange(pos0, pos0 + R, dtype=torch.int32)
+    crow = torch.ones(R, dtype=torch.int32)
+    kd, vd, qd, ld_, cd = kc.cuda(), vc.cuda(), qkv.cuda(), lens.cuda(), crow.cuda()
+    out = torch.full((R, heads * d), float("nan"), device="cuda")
+    kv = L.KV(kd.data_ptr(), vd.data_ptr(), L.VV_BF16 if kvdt == "bf16" else L.VV_F32, layers, rows, kv_heads, s_max, d)
+    L.check(l.vv_attn(qd.data_ptr(), ld, R, heads, C.byref(kv), layer, ld_.data_ptr(), cd.data_ptr(), out.data_ptr(), heads * d, None), "vv_attn")
+    torch.cuda.synchronize()
+    q = qkv[:, :heads * d].view(R, heads, d)
+    want = torch.empty(R, heads, d)
+    for h in range(heads):
+        kh = kc[layer, 1, h // (heads // kv_heads)].float()
+        vh = vc[layer, 1, h // (heads // kv_heads)].float()
+        sc = (q[:, h] @ kh.T) / d ** 0.5
+        mask = torch.arange(s_max)[None, :] > lens[:, None]
+        sc = sc.masked_fill(mask, float("-inf"))
+        want[:, h] = torch.softmax(sc, -1) @ vh
+    assert rel_rms(out.cpu().numpy(), want.reshape(R, -1).numpy()) < 2e-6

@@ -49,6 +49,7 @@ void vv_mfma_set_tiled_small_dual(int t);
 void vv_mfma_set_tiled_small_k(int k);
 void vv_mixer_set_rows(int on);
 void vv_mfma_set_mt_prefill(int mt);
+extern int g_attn_group;
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
   if (key && !strcmp(key, "gemv_long_cap")) { vv_gemv_stream_set_long(value, 0); return 0; }
   if (key && !strcmp(key, "gemv_long_ku")) { vv_gemv_stream_set_long(0, value); return 0; }
@@ -62,6 +63,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }
   if (key && !strcmp(key, "head_chain")) { vv_chain_set_head(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_bk128")) { vv_mfma_set_tiled_bk128(value); return 0; }
+  if (key && !strcmp(key, "attn_group")) { g_attn_group = value; return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_k")) { vv_mfma_set_tiled_small_k(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_dual")) { vv_mfma_set_tiled_small_dual(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_small")) { vv_mfma_set_tiled_small(value); return 0; }
@@ -790,6 +792,118 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* qkv, int64_t ld,
   }
 }
 
+// Prompt attention: one block per (query row, KV head).  The NQ query heads of a GQA group share every key / value load (the
+// per-head kernel above re-reads the cache once per q head: at 330 rows x 12 heads that is ~340 MB of L2 traffic per layer and
+// the whole cost of the kernel); loads run one batch of keys ahead of the arithmetic.
+template <typename KT, int EPL, int NQ>
+__global__ __launch_bounds__(256) void attn_group_kernel(const float* qkv, int64_t ld, vv_kv kv, int layer,
+                                                         const int* lens, const int* cache_rows, float* out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int U = 2;
+  const int r = blockIdx.y, kvh = blockIdx.x;
+  const int d = kv.head_dim;
+  const int G = d / EPL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane % G, gi = lane / G;
+  const int KPW = 64 / G;
+  const int n_keys = lens[r] + 1;
+  const int crow = cache_rows ? cache_rows[r] : r;
+  const int64_t base = ((((int64_t)layer * kv.rows + crow) * kv.kv_heads + kvh) * kv.s_max) * d;
+  const KT* kc = reinterpret_cast<const KT*>(kv.k) + base + gl * EPL;
+  const KT* vc = reinterpret_cast<const KT*>(kv.v) + base + gl * EPL;
+  const float scale = rsqrtf((float)d);
+  float q[NQ][EPL], acc[NQ][EPL], mmax[NQ], lsum[NQ];
+#pragma unroll
+  for (int hq = 0; hq < NQ; ++hq) {
+    const float* qp = qkv + (int64_t)r * ld + (kvh * NQ + hq) * d + gl * EPL;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) { q[hq][j] = qp[j] * scale; acc[hq][j] = 0.f; }
+    mmax[hq] = -INFINITY; lsum[hq] = 0.f;
+  }
+  const int stride = 4 * KPW;
+  att_raw kr[U], vr[U];
+  auto issue = [&](int s0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sc = min(s0 + u * stride + gi, n_keys - 1);
+      kr[u] = *reinterpret_cast<const att_raw*>(kc + (int64_t)sc * d);
+      vr[u] = *reinterpret_cast<const att_raw*>(vc + (int64_t)sc * d);
+    }
+  };
+  issue(wave * KPW);
+  for (int s0 = wave * KPW; s0 < n_keys; s0 += U * stride) {
+    att_raw kc_[U], vc_[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { kc_[u] = kr[u]; vc_[u] = vr[u]; }
+    if (s0 + U * stride < n_keys) issue(s0 + U * stride);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool valid = s0 + u * stride + gi < n_keys;
+      float kx[EPL], vx[EPL];
+      unpack_epl<KT, EPL>(kc_[u], kx);
+      unpack_epl<KT, EPL>(vc_[u], vx);
+#pragma unroll
+      for (int hq = 0; hq < NQ; ++hq) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) dot = fmaf(q[hq][j], kx[j], dot);
+        dot = group_dot_sum(dot, G);
+        // the running maximum moves O(log n) times: the rescale is skipped (wave-uniformly) when no key group's maximum moved
+        const float mn = valid ? fmaxf(mmax[hq], dot) : mmax[hq];
+        if (__builtin_amdgcn_ballot_w64(mn != mmax[hq]) != 0) {
+          const float corr = __expf(mmax[hq] - mn);      // exp(-inf) = 0 on the first key; 1 where the maximum stayed
+          lsum[hq] *= (mn == mmax[hq]) ? 1.f : corr;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) acc[hq][j] *= (mn == mmax[hq]) ? 1.f : corr;
+          mmax[hq] = mn;
+        }
+        const float pr = valid ? __expf(dot - mn) : 0.f;
+        lsum[hq] += pr;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) acc[hq][j] = fmaf(pr, vx[j], acc[hq][j]);
+      }
+    }
+  }
+  // merge the 4*KPW key groups per q head: sm = [ngroups][NQ][2 + d]
+  const int ng = 4 * KPW;
+  const int g = wave * KPW + gi;
+#pragma unroll
+  for (int hq = 0; hq < NQ; ++hq) {
+    float* rec = sm + ((int64_t)g * NQ + hq) * (d + 2);
+    if (gl == 0) { rec[0] = mmax[hq]; rec[1] = lsum[hq]; }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) rec[2 + gl * EPL + j] = acc[hq][j];
+  }
+  __syncthreads();
+  for (int i = tid; i < NQ * d; i += blockDim.x) {
+    const int hq = i / d, e = i - hq * d;
+    float M = -INFINITY;
+    for (int gg = 0; gg < ng; ++gg) M = fmaxf(M, sm[((int64_t)gg * NQ + hq) * (d + 2)]);
+    float num = 0.f, den = 0.f;
+    for (int gg = 0; gg < ng; ++gg) {
+      const float* rr = sm + ((int64_t)gg * NQ + hq) * (d + 2);
+      const float wgt = (rr[0] == -INFINITY) ? 0.f : expf(rr[0] - M);
+      den = fmaf(rr[1], wgt, den);
+      num = fmaf(rr[2 + e], wgt, num);
+    }
+    out[(int64_t)r * ldo + (kvh * NQ + hq) * d + e] = num / den;
+  }
+}
+
+template <int NQ>
+bool launch_attn_group(const float* qkv, int64_t ld, const vv_kv* kv, int layer, const int* lens, const int* cache_rows, float* out,
+                       int64_t ldo, int R, hipStream_t s) {
+  const int d = kv->head_dim, epl = kv->kvdt == VV_F32 ? 4 : 8, ng = 4 * (64 / (d / epl));
+  const size_t lds = (size_t)ng * NQ * (d + 2) * sizeof(float);
+  if (lds > 65536) return false;
+  dim3 grid(kv->kv_heads, R);
+  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_group_kernel<float, 4, NQ>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+  else hipLaunchKernelGGL((attn_group_kernel<bf16_t, 8, NQ>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+  return true;
+}
+
+int g_attn_group = 1;      // tuning hook "attn_group": 0 = one block per q head for every row count
+
 extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const int* lens,
                        const int* cache_rows, float* out, int64_t ldo, vv_stream_t stream) {
   if (!qkv || !kv || !lens || !out) return vv_set_error(VV_E_ARG, "vv_attn: null pointer");
@@ -801,6 +915,14 @@ extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const
   const size_t lds = (size_t)ng * (d + 2) * sizeof(float);
   if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn: LDS %zu too large", lds);
   hipStream_t s = (hipStream_t)stream;
+  if (g_attn_group && R >= 8 && ((uintptr_t)qkv % 16 == 0) && (ld_qkv % 4 == 0)) {      // prompt-sized row counts: share K/V loads across the GQA group
+    const int nq = heads / kv->kv_heads;
+    bool done = false;
+    if (nq == 2) done = launch_attn_group<2>(qkv, ld_qkv, kv, layer, lens, cache_rows, out, ldo, R, s);
+    else if (nq == 6) done = launch_attn_group<6>(qkv, ld_qkv, kv, layer, lens, cache_rows, out, ldo, R, s);
+    else if (nq == 7) done = launch_attn_group<7>(qkv, ld_qkv, kv, layer, lens, cache_rows, out, ldo, R, s);
+    if (done) { VV_CHECK_LAUNCH("vv_attn"); return 0; }
+  }
   dim3 grid(heads, R);
   if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_kernel<float, 4>), grid, dim3(256), lds, s, qkv, ld_qkv, heads, *kv, layer, lens, cache_rows, out, ldo);
   else hipLaunchKernelGGL((attn_kernel<bf16_t, 8>), grid, dim3(256), lds, s, qkv, ld_qkv, heads, *kv, layer, lens, cache_rows, out, ldo);
