@@ -14,9 +14,8 @@ lib = L.load()
 eng = m.engine
 x0 = torch.randn(330, cfg.hidden, device="cuda")
 voice = wl["speech_tensors"][0].cuda()
-for small, sk in ((200, 0), (200, 256), (200, 1000), (200, 0), (200, 256)):
-    lib.vv_tune(b"mfma_tiled_small", small)
-    lib.vv_tune(b"mfma_tiled_small_dual", sk)
+for small, sk in ((200, 0), (200, 1), (200, 0), (200, 1)):
+    lib.vv_tune(b"mfma_tiled_dual_bk64", sk)
     eng.begin_sequence(1024, [cfg.vocab-4, cfg.vocab-3, cfg.vocab-2, cfg.vocab-1])
     for _ in range(2): eng.prefill(x0, row=0)
     eng.stream.synchronize()
@@ -31,4 +30,4 @@ for small, sk in ((200, 0), (200, 256), (200, 1000), (200, 0), (200, 256)):
     eng.stream.synchronize()
     tv = (time.perf_counter()-t0)/3*1e3
     r = bench.first_chunk_leg(m, wl, 2.0, runs=5)
-    print(f"mfma_tiled_small={small} dual<{sk}: prefill {tp:.2f} ms, voice encode {tv:.2f} ms, first chunk {r['p50_ms']}")
+    print(f"mfma_tiled_small={small} dual_bk64={sk}: prefill {tp:.2f} ms, voice encode {tv:.2f} ms, first chunk {r['p50_ms']}")

@@ -45,6 +45,7 @@ void vv_mfma_set_mt(int mt);
 void vv_mfma_set_tiled_rows(int r);
 void vv_mfma_set_tiled_bk128(int on);
 void vv_mfma_set_tiled_small(int t);
+void vv_mfma_set_tiled_dual_bk64(int on);
 void vv_mfma_set_tiled_small_dual(int t);
 void vv_mfma_set_tiled_small_k(int k);
 void vv_mixer_set_rows(int on);
@@ -65,6 +66,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "mfma_tiled_bk128")) { vv_mfma_set_tiled_bk128(value); return 0; }
   if (key && !strcmp(key, "attn_group")) { g_attn_group = value; return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_k")) { vv_mfma_set_tiled_small_k(value); return 0; }
+  if (key && !strcmp(key, "mfma_tiled_dual_bk64")) { vv_mfma_set_tiled_dual_bk64(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_dual")) { vv_mfma_set_tiled_small_dual(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_small")) { vv_mfma_set_tiled_small(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_rows")) { vv_mfma_set_tiled_rows(value); return 0; }

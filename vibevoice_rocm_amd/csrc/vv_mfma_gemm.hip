@@ -436,6 +436,7 @@ constexpr size_t tiled_lds() { return (size_t)(DUAL ? 3 : 2) * 2 * TM * (BK + 8)
 
 int g_tiled_bk128 = 1;     // long-K slabs for the non-dual tiled kernel (tuning hook "mfma_tiled_bk128")
 int g_tiled_small = 200;  // below this many 128 x 128 tiles a long-K GEMM uses 64 x 64 tiles (tuning hook "mfma_tiled_small"; 0 = never)
+int g_tiled_dual_bk64 = 1;
 int g_tiled_small_k = 1024;     // shortest K for the 64 x 64 variant (tuning hook "mfma_tiled_small_k")
 int g_tiled_small_dual = 256;   // same for the dual (SwiGLU gate/up) GEMM: prefill gate/up is 210 tiles (tuning hook "mfma_tiled_small_dual")
 int g_tiled_rows = 32;     // fewest rows for the tiled kernel (tuning hook "mfma_tiled_rows"; 0 = never); it also needs >= 24 tiles
@@ -479,13 +480,14 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && enough_tiles && a.n % TG_BN == 0 && a.k % 32 == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
     dim3 grid(a.n / TG_BN, (a.m + TG_BM - 1) / TG_BM);
     const size_t lds_d = tiled_lds<true, 32>(), lds_l = tiled_lds<false, 128>(), lds_s = tiled_lds<false, 32>();
-    const size_t lds_q = tiled_lds<false, 128, 64>(), lds_qd = tiled_lds<true, 32, 64>();
+    const size_t lds_q = tiled_lds<false, 128, 64>(), lds_qd = tiled_lds<true, 32, 64>(), lds_qd64 = tiled_lds<true, 64, 64>();
     // a long-K GEMM on a few dozen 128 x 128 tiles (prefill down-projection: 36 tiles x 70 K rounds; the T = 200 stage of a voice-
     // prompt encode: 32 tiles x 64 rounds) leaves most CUs idle behind a serial K loop: 64 x 64 tiles give 4x the workgroups,
     // each with a quarter of the MFMA / LDS work per round and a 4-slab-deep register prefetch
     if (a.w2 && (long)grid.x * grid.y < g_tiled_small_dual) {
       dim3 gq(a.n / 64, (a.m + 63) / 64);
-      hipLaunchKernelGGL((mfma_tiled_kernel<true, 32, 64>), gq, dim3(256), lds_qd, s, a);
+      if (a.k % 64 == 0 && g_tiled_dual_bk64) hipLaunchKernelGGL((mfma_tiled_kernel<true, 64, 64>), gq, dim3(256), lds_qd64, s, a);
+      else hipLaunchKernelGGL((mfma_tiled_kernel<true, 32, 64>), gq, dim3(256), lds_qd, s, a);
       return 1;
     }
     if (!a.w2 && g_tiled_small > 0 && a.k % 128 == 0 && a.k >= g_tiled_small_k && (long)grid.x * grid.y < g_tiled_small) {
@@ -534,14 +536,16 @@ void vv_mfma_set_tiled_bk128(int on) { g_tiled_bk128 = on; }
 void vv_mfma_set_tiled_small(int t) { g_tiled_small = t; }
 void vv_mfma_set_tiled_small_k(int k) { g_tiled_small_k = k; }
 void vv_mfma_set_tiled_small_dual(int t) { g_tiled_small_dual = t; }
+void vv_mfma_set_tiled_dual_bk64(int on) { g_tiled_dual_bk64 = on; }
 void vv_mfma_set_mt_prefill(int mt) { g_mt_prefill = mt; g_mt_prefill_xb = mt; }
 
 // graph capture must not see the one-time hipFuncSetAttribute calls: the library warms them here
 int vv_mfma_gemm_init() {
   hipError_t e;
   const int lds_d = (int)tiled_lds<true, 32>(), lds_l = (int)tiled_lds<false, 128>(), lds_s = (int)tiled_lds<false, 32>();
-  const int lds_q = (int)tiled_lds<false, 128, 64>(), lds_qd = (int)tiled_lds<true, 32, 64>();
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_qd) != hipSuccess ||
+  const int lds_q = (int)tiled_lds<false, 128, 64>(), lds_qd = (int)tiled_lds<true, 32, 64>(), lds_qd64 = (int)tiled_lds<true, 64, 64>();
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_qd64) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<true, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_qd) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_l) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tiled_kernel<false, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_s) != hipSuccess ||
