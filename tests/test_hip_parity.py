@@ -253,7 +253,7 @@ def test_block1d_single_launch_vs_torch(lib, C_, T):
 
 @pytest.mark.parametrize("m,n,k,dual", [(330, 2048, 1536, False), (200, 8960, 1536, True), (129, 1536, 8960, False), (128, 128, 32, False), (513, 256, 96, True),
                                         (1024, 256, 1024, False), (2500, 128, 512, False), (1300, 384, 96, True),
-                                        (330, 1536, 8960, False), (203, 2048, 8192, False), (65, 3072, 2048, False)])
+                                        (330, 1536, 8960, False), (203, 2048, 8192, False), (65, 3072, 2048, False), (203, 64, 14336, False), (64, 192, 8192, False)])
 def test_prefill_gemm_bf16_activations(lib, m, n, k, dual):
     """vv_linear with VV_LIN_X_BF16 at prompt sizes (the direct-stream matrix-core GEMM of the prefill, 128-row strips) and at
     voice-prompt sizes (>= 1024 rows: the 128 x 128 LDS-tiled GEMM; long K on few tiles: its 64 x 64 variant): bias / SwiGLU / residual epilogues against torch on the same

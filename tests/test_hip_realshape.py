@@ -173,6 +173,31 @@ def test_voice_prompt_encode_1p5b_vs_oracle(big):
     assert rel_rms(got.cpu().numpy(), ref.numpy()) < 2e-2
 
 
+def test_long_voice_prompt_head_conv_route_1p5b(big):
+    """A 70-frame utterance: the 2048 -> 64 head conv (K = 14336) and the few-tile long-K FFN GEMMs of the last stages run on the
+    64 x 64-tile kernel.  Size-independent check: the same encode with that kernel switched off (streaming kernels, identical bf16
+    operand rounding, different summation order) agrees to accumulation-order noise; plus shape and finiteness."""
+    from vibevoice_rocm_amd import _lib as L
+    cfg, sd, m = big
+    eng = m.engine
+    lib = L.load()
+    g = torch.Generator().manual_seed(18)
+    wav = 0.1 * torch.randn(70 * cfg.hop + 123, generator=g)
+    got = eng.acoustic_encode(wav)
+    eng.stream.synchronize()            # the engine runs on its own stream: results are read only after it drains
+    got = got.cpu()
+    try:
+        lib.vv_tune(b"mfma_tiled_small", 0)
+        ref = eng.acoustic_encode(wav)
+        eng.stream.synchronize()
+        ref = ref.cpu()
+    finally:
+        lib.vv_tune(b"mfma_tiled_small", 200)
+    assert tuple(got.shape) == (71, cfg.ac_dim) and bool(torch.isfinite(got).all())
+    # bf16 hidden activations: a different summation order flips roundings of intermediate tiles (measured 1.5e-3 through 40+ layers)
+    assert rel_rms(got.numpy(), ref.numpy()) < 1e-2
+
+
 class _Tok:
     def __init__(self, v):
         self.speech_start_id, self.speech_end_id, self.speech_diffusion_id, self.eos_token_id = v - 4, v - 3, v - 2, v - 1

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void mfma_tiled_kernel(const vv_lin_args a) {
 template <bool DUAL, int BK, int TM = 128>
 constexpr size_t tiled_lds() { return (size_t)(DUAL ? 3 : 2) * 2 * TM * (BK + 8) * 2; }
 
+constexpr size_t tiled_lds_q() { return tiled_lds<false, 128, 64>(); }
 int g_tiled_bk128 = 1;     // long-K slabs for the non-dual tiled kernel (tuning hook "mfma_tiled_bk128")
 int g_tiled_small = 200;  // below this many 128 x 128 tiles a long-K GEMM uses 64 x 64 tiles (tuning hook "mfma_tiled_small"; 0 = never)
 int g_tiled_dual_bk64 = 1;
@@ -477,6 +478,14 @@ int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s) {
   // the tiled kernel needs enough 128 x 128 tiles to occupy the chip's memory system (prefill: 36-210, voice-prompt encode: hundreds,
   // hoisted adaLN: 36); a conv-stage GEMM with 4 tiles stays on the streaming kernel (T = 200, C = 256: 8 us there, 25 us tiled)
   const bool enough_tiles = (long)(a.n / TG_BN) * ((a.m + TG_BM - 1) / TG_BM) >= 24;
+  // a narrow output over a very long K (the 2048 -> 64 head conv of a whole-utterance encode: K = 14336, 203 rows): a handful of
+  // 64 x 64 tiles, each a fast 128-column-slab K loop, instead of 14 streaming workgroups walking K in 16-element steps (216 -> 50 us)
+  if (g_tiled_rows > 0 && g_tiled_small > 0 && xb && !a.w2 && !enough_tiles && a.m >= 64 && a.n % 64 == 0 && a.k % 128 == 0 && a.k >= 8192 &&
+      a.ldx % 8 == 0) {
+    dim3 gq(a.n / 64, (a.m + 63) / 64);
+    hipLaunchKernelGGL((mfma_tiled_kernel<false, 128, 64>), gq, dim3(256), tiled_lds_q(), s, a);
+    return 1;
+  }
   if (g_tiled_rows > 0 && xb && a.m >= g_tiled_rows && enough_tiles && a.n % TG_BN == 0 && a.k % 32 == 0 && a.ldx % 8 == 0 && a.m <= 65535 * TG_BM) {
     dim3 grid(a.n / TG_BN, (a.m + TG_BM - 1) / TG_BM);
     const size_t lds_d = tiled_lds<true, 32>(), lds_l = tiled_lds<false, 128>(), lds_s = tiled_lds<false, 32>();

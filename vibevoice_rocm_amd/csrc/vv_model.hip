@@ -449,6 +449,11 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
           tiles >= 24 && in_el * 2 <= hel * 4 && ((uintptr_t)cv.w % 16 == 0)) {
         VV_TRY(vv_cast_rows_bf16(pad, cv.cin, (int)need, cv.cin, VV_PRO_NONE, nullptr, 0.f, hid, cv.cin, stream));
         a.x = hid; a.flags = VV_LIN_X_BF16;
+      } else if (net->wdt == VV_BF16 && is_head && Tout >= 64 && cv.cout % 64 == 0 && (cv.kk * cv.cin) % 128 == 0 && cv.kk * cv.cin >= 8192 &&
+                 (cv.stride * cv.cin) % 8 == 0 && cv.cin % 8 == 0 && in_el * 2 <= hel * 4 && ((uintptr_t)cv.w % 16 == 0)) {
+        // the head conv of a long sequence (few output channels, K = 7 x 2048): same cast, 64 x 64 tiles over the long K
+        VV_TRY(vv_cast_rows_bf16(pad, cv.cin, (int)need, cv.cin, VV_PRO_NONE, nullptr, 0.f, hid, cv.cin, stream));
+        a.x = hid; a.flags = VV_LIN_X_BF16;
       }
     }
     VV_TRY(vv_linear(&a, stream));
