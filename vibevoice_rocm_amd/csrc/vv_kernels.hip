@@ -797,14 +797,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* qkv, int64_t ld,
 // Prompt attention: one block per (query row, KV head).  The NQ query heads of a GQA group share every key / value load (the
 // per-head kernel above re-reads the cache once per q head: at 330 rows x 12 heads that is ~340 MB of L2 traffic per layer and
 // the whole cost of the kernel); loads run one batch of keys ahead of the arithmetic.
-template <typename KT, int EPL, int NQ>
+template <typename KT, int EPL, int NQ, int GT>      // GT: lanes per key when known at compile time (head_dim 128), 0 = from kv.head_dim
 __global__ __launch_bounds__(256) void attn_group_kernel(const float* qkv, int64_t ld, vv_kv kv, int layer,
                                                          const int* lens, const int* cache_rows, float* out, int64_t ldo) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int U = 2;
   const int r = blockIdx.y, kvh = blockIdx.x;
-  const int d = kv.head_dim;
-  const int G = d / EPL;
+  const int d = GT ? GT * EPL : kv.head_dim;
+  const int G = GT ? GT : d / EPL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gl = lane % G, gi = lane / G;
   const int KPW = 64 / G;
@@ -899,8 +899,13 @@ bool launch_attn_group(const float* qkv, int64_t ld, const vv_kv* kv, int layer,
   const size_t lds = (size_t)ng * NQ * (d + 2) * sizeof(float);
   if (lds > 65536) return false;
   dim3 grid(kv->kv_heads, R);
-  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_group_kernel<float, 4, NQ>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
-  else hipLaunchKernelGGL((attn_group_kernel<bf16_t, 8, NQ>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+  if (kv->kvdt == VV_F32) {
+    if (d == 128) hipLaunchKernelGGL((attn_group_kernel<float, 4, NQ, 32>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+    else hipLaunchKernelGGL((attn_group_kernel<float, 4, NQ, 0>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+  } else {
+    if (d == 128) hipLaunchKernelGGL((attn_group_kernel<bf16_t, 8, NQ, 16>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+    else hipLaunchKernelGGL((attn_group_kernel<bf16_t, 8, NQ, 0>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
+  }
   return true;
 }
 
