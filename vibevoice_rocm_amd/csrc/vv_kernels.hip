@@ -877,14 +877,22 @@ __global__ __launch_bounds__(256) void attn_group_kernel(const float* qkv, int64
     for (int j = 0; j < EPL; ++j) rec[2 + gl * EPL + j] = acc[hq][j];
   }
   __syncthreads();
+  // the merge weight of a (key group, q head) pair is computed once, not once per output element
+  float* wts = sm + (int64_t)ng * NQ * (d + 2);                       // [NQ][ng]
+  if (tid < NQ * ng) {
+    const int hq = tid / ng, gg = tid - hq * ng;
+    float M = -INFINITY;
+    for (int g2 = 0; g2 < ng; ++g2) M = fmaxf(M, sm[((int64_t)g2 * NQ + hq) * (d + 2)]);
+    const float mg = sm[((int64_t)gg * NQ + hq) * (d + 2)];
+    wts[tid] = (mg == -INFINITY) ? 0.f : expf(mg - M);
+  }
+  __syncthreads();
   for (int i = tid; i < NQ * d; i += blockDim.x) {
     const int hq = i / d, e = i - hq * d;
-    float M = -INFINITY;
-    for (int gg = 0; gg < ng; ++gg) M = fmaxf(M, sm[((int64_t)gg * NQ + hq) * (d + 2)]);
     float num = 0.f, den = 0.f;
     for (int gg = 0; gg < ng; ++gg) {
       const float* rr = sm + ((int64_t)gg * NQ + hq) * (d + 2);
-      const float wgt = (rr[0] == -INFINITY) ? 0.f : expf(rr[0] - M);
+      const float wgt = wts[hq * ng + gg];
       den = fmaf(rr[1], wgt, den);
       num = fmaf(rr[2 + e], wgt, num);
     }
@@ -896,8 +904,8 @@ template <int NQ>
 bool launch_attn_group(const float* qkv, int64_t ld, const vv_kv* kv, int layer, const int* lens, const int* cache_rows, float* out,
                        int64_t ldo, int R, hipStream_t s) {
   const int d = kv->head_dim, epl = kv->kvdt == VV_F32 ? 4 : 8, ng = 4 * (64 / (d / epl));
-  const size_t lds = (size_t)ng * NQ * (d + 2) * sizeof(float);
-  if (lds > 65536) return false;
+  const size_t lds = ((size_t)ng * NQ * (d + 2) + (size_t)NQ * ng) * sizeof(float);
+  if (lds > 65536 || NQ * ng > 256) return false;
   dim3 grid(kv->kv_heads, R);
   if (kv->kvdt == VV_F32) {
     if (d == 128) hipLaunchKernelGGL((attn_group_kernel<float, 4, NQ, 32>), grid, dim3(256), lds, s, qkv, ld, *kv, layer, lens, cache_rows, out, ldo);
