@@ -952,13 +952,13 @@ extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const
 // k, v at slot pos.  512 threads, 4 keys in flight per lane group: S ~ 500 is four round trips instead of thirty.
 // ---------------------------------------------------------------------------------------------------------------
 #define ATT_UNR 4
-template <typename KT, int EPL>
+template <typename KT, int EPL, int GT>      // GT: lanes per key when known at compile time (head_dim 128), 0 = from kv.head_dim
 __global__ __launch_bounds__(1024) void attn_fused_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer,
                                                          const float2* rope, const int* lens, float* out, int64_t ldo) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int r = blockIdx.y, h = blockIdx.x;
-  const int d = kv.head_dim, half = d >> 1;
-  const int G = d / EPL;
+  const int d = GT ? GT * EPL : kv.head_dim, half = d >> 1;
+  const int G = GT ? GT : d / EPL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NW = 16;
   const int gl = lane % G, gi = lane / G;
@@ -1099,8 +1099,13 @@ extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads
   if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn_decode: LDS %zu too large", lds);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(heads, R);
-  if (kv->kvdt == VV_F32) hipLaunchKernelGGL((attn_fused_kernel<float, 4>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
-  else hipLaunchKernelGGL((attn_fused_kernel<bf16_t, 8>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  if (kv->kvdt == VV_F32) {
+    if (d == 128) hipLaunchKernelGGL((attn_fused_kernel<float, 4, 32>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+    else hipLaunchKernelGGL((attn_fused_kernel<float, 4, 0>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  } else {
+    if (d == 128) hipLaunchKernelGGL((attn_fused_kernel<bf16_t, 8, 16>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+    else hipLaunchKernelGGL((attn_fused_kernel<bf16_t, 8, 0>), grid, dim3(1024), lds, s, qkv, ld_qkv, heads, *kv, layer, inv_freq, lens, out, ldo);
+  }
   VV_CHECK_LAUNCH("vv_attn_decode");
   return 0;
 }
