@@ -192,7 +192,7 @@ typedef struct vv_head_layer {
   vv_w8 q_gate, q_up, q_down;
 } vv_head_layer;
 
-#define VV_HEAD_CHAIN 1 /* vv_head.flags: run the solver loop as ONE persistent chained kernel (vv_chain.hip; experimental, needs the GPU to itself) instead of one launch per GEMV */
+#define VV_HEAD_CHAIN 1 /* vv_head.flags: run the solver loop as ONE persistent chained kernel instead of one launch per GEMV.  Experimental (vv_chain.hip: spin-wait grid barriers, needs the GPU to itself): honoured only by a library built with -DVV_WITH_CHAIN, ignored by the product build */
 typedef struct vv_head {
   int wdt, D, ffn, layers, latent, cond_dim;
   float eps;

@@ -8,9 +8,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("vv_kernels.hip", "vv_gemv_stream.hip", "vv_mfma_gemm.hip", "vv_chain.hip", "vv_block1d.hip", "vv_model.hip")]
+# VV_WITH_CHAIN=1 also builds the experimental persistent chained head kernel (vv_chain.hip: spin-wait grid barriers, needs the GPU
+# to itself; a measured dead end kept for the record).  The product library is built without it.
+WITH_CHAIN = os.environ.get("VV_WITH_CHAIN", "0") == "1"
+SRC = [os.path.join(HERE, "csrc", f) for f in ("vv_kernels.hip", "vv_gemv_stream.hip", "vv_mfma_gemm.hip", "vv_block1d.hip", "vv_attn_prefill.hip", "vv_model.hip")
+       if os.path.exists(os.path.join(HERE, "csrc", f))]
+if WITH_CHAIN:
+    SRC.append(os.path.join(HERE, "csrc", "vv_chain.hip"))
 HDR = [os.path.join(ROOT, "include", "vv_hip.h"), os.path.join(HERE, "csrc", "vv_common.h")]
 OUT = os.path.join(HERE, "libvv_hip.so")
+OBJDIR = os.path.join(HERE, "csrc", "build")
 
 
 def find_hipcc() -> str:
@@ -27,11 +34,32 @@ def up_to_date() -> bool:
     return all(os.path.getmtime(p) <= t for p in SRC + HDR)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def _obj(src: str) -> str:
+    return os.path.join(OBJDIR, os.path.basename(src) + (".chain.o" if WITH_CHAIN else ".o"))
+
+
+def build(force: bool = False, verbose: bool = True, jobs: int = 6) -> str:
+    """One object per translation unit (compiled in parallel, rebuilt only when the unit or a header changed), then one link."""
     if not force and up_to_date():
         return OUT
-    cmd = [find_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"), *SRC, "-o", OUT]
+    os.makedirs(OBJDIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *(["-DVV_WITH_CHAIN"] if WITH_CHAIN else []),
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+    hipcc = find_hipcc()
+    hdr_t = max(os.path.getmtime(p) for p in HDR)
+    todo = [s for s in SRC if force or not os.path.exists(_obj(s)) or os.path.getmtime(_obj(s)) < max(os.path.getmtime(s), hdr_t)]
+    procs = []
+    for s in todo:
+        cmd = [hipcc, *flags, "-c", s, "-o", _obj(s)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd)))
+        while sum(p.poll() is None for _, p in procs) >= jobs:
+            procs[0][1].wait() if procs[0][1].poll() is None else next(p for _, p in procs if p.poll() is None).wait()
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(os.path.basename(f) for f in failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in SRC], "-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

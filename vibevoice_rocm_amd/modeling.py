@@ -300,8 +300,8 @@ class VibeVoiceForConditionalGenerationInference:
                     deliver()
                     audio_streamer.end()
                 break
-            if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and any(audio_streamer.finished_flags):
-                break                                                                           # :441-445
+            if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and audio_streamer.finished_flags[sample_idx]:
+                break                                                                           # :441-445 (this sample's stream was ended externally)
             if len(seq) >= max_length:                                                          # :452-457
                 reach_max = True
                 break
