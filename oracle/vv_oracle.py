@@ -169,20 +169,26 @@ def dpm_step(c: dict, x: Tensor, v: Tensor, m_prev: Optional[Tensor], noise: Opt
 HEAD = "model.prediction_head."
 
 
-def timestep_embedding(t: Tensor, dim: int = 256, max_period: float = 10000.0) -> Tensor:
-    """[cos | sin] sinusoid.  modular_vibevoice_diffusion_head.py:66-88."""
+def timestep_embedding(t: Tensor, dim: int = 256, max_period: float = 10000.0, bf16_t: bool = False) -> Tensor:
+    """[cos | sin] sinusoid.  modular_vibevoice_diffusion_head.py:66-88.
+    bf16_t: the two roundings the reference's bf16 run applies around it - `t` arrives cast to the activation dtype
+    (modeling_vibevoice_inference.py:703: 949 -> 948, 999 -> 1000, ...) and the embedding is cast back to it (:88)."""
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
-    args = t[:, None].float() * freqs[None]
-    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    t = t.float()
+    if bf16_t:
+        t = t.to(torch.bfloat16).float()
+    args = t[:, None] * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    return emb.to(torch.bfloat16).float() if bf16_t else emb
 
 
-def head_forward(W: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, cond: Tensor) -> Tensor:
+def head_forward(W: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, cond: Tensor, bf16_t: bool = False) -> Tensor:
     """VibeVoiceDiffusionHead.forward.  modular_vibevoice_diffusion_head.py:254-280 (HeadLayer :158-161,
     FinalLayer :184-188, TimestepEmbedder :90-93)."""
     p = HEAD
     h = linear(x, W[p + "noisy_images_proj.weight"])
-    te = timestep_embedding(t, W[p + "t_embedder.mlp.0.weight"].shape[1])
+    te = timestep_embedding(t, W[p + "t_embedder.mlp.0.weight"].shape[1], bf16_t=bf16_t)
     te = linear(silu(linear(te, W[p + "t_embedder.mlp.0.weight"])), W[p + "t_embedder.mlp.2.weight"])
     c = linear(cond, W[p + "cond_proj.weight"]) + te
     for l in range(cfg["head_layers"]):
@@ -198,7 +204,7 @@ def head_forward(W: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, cond: Te
 
 
 def sample_speech_tokens(W, cfg, cond: Tensor, ncond: Tensor, noise: Tensor, cfg_scale: float, n_steps: int,
-                         tables=None, algorithm: str = "dpmsolver++", sde_noise: Optional[Tensor] = None) -> Tensor:
+                         tables=None, algorithm: str = "dpmsolver++", sde_noise: Optional[Tensor] = None, bf16_t: bool = False) -> Tensor:
     """CFG DPM-Solver++ sampling loop with INJECTED noise [n, latent] (the reference draws
     randn(2n, latent) on the CPU and only ever uses rows [:n]).  modeling_vibevoice_inference.py:695-708.
     SDE variant: `sde_noise` [n_steps, n, latent] = rows [:n] of the [2n, latent] variance noise scheduler.step draws per step
@@ -213,7 +219,7 @@ def sample_speech_tokens(W, cfg, cond: Tensor, ncond: Tensor, noise: Tensor, cfg
     for i, t in enumerate(timesteps):
         combined = torch.cat([x, x], dim=0)
         tt = torch.full((2 * n,), float(t), dtype=torch.float32)
-        eps = head_forward(W, cfg, combined, tt, condition)
+        eps = head_forward(W, cfg, combined, tt, condition, bf16_t=bf16_t)
         ce, ue = eps[:n], eps[n:]
         half = ue + cfg_scale * (ce - ue)
         x, m_prev = dpm_step(coefs[i], x, half, m_prev, None if sde_noise is None else sde_noise[i].float())
@@ -483,14 +489,15 @@ class GenerateResult:
 def generate(W, cfg: dict, input_ids: List[int], speech_input_mask: Optional[Tensor], speech_embeds: Optional[Tensor],
              special: dict, noise: Tensor, cfg_scale: float = 1.3, n_steps: int = 10, max_length_times: float = 2.0,
              forced_tokens: Optional[List[int]] = None, max_new_tokens: Optional[int] = None,
-             keep_trace: bool = False) -> GenerateResult:
+             keep_trace: bool = False, bf16_t: bool = False) -> GenerateResult:
     """Batch-1 restatement of generate().  `special` = dict(speech_start, speech_end, speech_diffusion, eos[, bos]).
     `noise` [F, latent] is consumed one row per diffusion frame (replaces the CPU randn at :699).
     `forced_tokens` overrides the argmax (bench / random-weight runs) but the logits
     are still computed.  Negative branch (:377-384, :547-563, :575-587): its context is every
     embedding the positive branch consumed since the last speech_start; the reference's reset
     (mask all slots, unmask only the next one => position 0, attends to nothing else) is a truncation
-    to length 0 — pinned against the reference's own mask surgery by the loop_trace fixture."""
+    to length 0 — pinned against the reference's own mask surgery by the loop_trace fixture.
+    `bf16_t`: the timestep roundings of the reference's bf16 run (see timestep_embedding)."""
     res = GenerateResult()
     emb = W[LLM + "embed_tokens.weight"]
     ids = list(input_ids)
@@ -530,7 +537,7 @@ def generate(W, cfg: dict, input_ids: List[int], speech_input_mask: Optional[Ten
             neg_in = x_in[-1:] if step > 0 else emb[special["speech_start"]].float()[None]
             nhidden = llm_forward(W, cfg, neg_in, neg_kv, neg_kv.length)[-1]       # :575-587
             latent = sample_speech_tokens(W, cfg, hidden[None], nhidden[None], noise[frame][None], cfg_scale,
-                                          n_steps, tables)                         # :627-631
+                                          n_steps, tables, bf16_t=bf16_t)          # :627-631
             scaled = latent / W["model.speech_scaling_factor"].float() - W["model.speech_bias_factor"].float()
             wav = tokenizer_decoder(W, cfg, scaled.t(), ac_state)                  # [1, 3200]   :634-641
             sem = semantic_encode(W, cfg, wav, sem_state)                          # [1, 128]    :656-662

@@ -26,6 +26,66 @@ def test_library_exports_every_declared_symbol():
     assert lib.vv_abi_version() == 2
 
 
+def test_integration_md_struct_mirrors_match_the_library():
+    """The ctypes mirrors INTEGRATION.md shows a reference maintainer are executed and checked against the built library
+    (vv_sizeof) and against the product's own mirrors (field names, order, sizes): a stale snippet misreads device pointers."""
+    import ctypes as C
+    from vibevoice_rocm_amd import _lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", md, flags=re.S) if b.lstrip().startswith("# abi-mirror")]
+    assert len(blocks) == 1
+    ns = {}
+    exec(blocks[0], ns)
+    lib = _lib.load()
+    found = {k: v for k, v in ns.items() if isinstance(v, type) and issubclass(v, C.Structure) and k.startswith("vv_")}
+    assert {"vv_head_layer", "vv_head", "vv_dpm_coef"} <= set(found)
+    mirrors = dict(_lib._STRUCTS, vv_w8=_lib.W8)
+    for name, cls in found.items():
+        if name != "vv_w8":
+            assert lib.vv_sizeof(name.encode()) == C.sizeof(cls), (name, lib.vv_sizeof(name.encode()), C.sizeof(cls))
+        ours = mirrors[name]
+        assert [f[0] for f in cls._fields_] == [f[0] for f in ours._fields_], name
+        assert [C.sizeof(f[1]) for f in cls._fields_] == [C.sizeof(f[1]) for f in ours._fields_], name
+    assert f"ABI v{lib.vv_abi_version()}" in blocks[0]
+
+
+def test_checkpoint_dir_roundtrip_reference_layout(tmp_path):
+    """save_checkpoint_dir writes the reference's layout (config.json schema of vibevoice/configs/*.json incl. the vibepod_* model_type
+    keys, preprocessor_config.json, safetensors shards + index as scripts/convert_nnscaler_checkpoint_to_transformers.py:92-123 does);
+    VVConfig.from_pretrained / load_state_dict_from_dir / VibeVoiceProcessor.from_pretrained read it back (CPU part of the drop-in
+    path; the GPU part is tests/test_hip_configs.py::test_drop_in_checkpoint_dir_through_reference_import_paths)."""
+    import dataclasses
+    import json
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.modeling import load_state_dict_from_dir, save_checkpoint_dir
+    from vibevoice_rocm_amd.processor import SyntheticTokenizer, VibeVoiceProcessor
+    from vibevoice_rocm_amd.synth import synth_state_dict
+    for tie in (True, False):
+        cfg = dataclasses.replace(VVConfig.preset("tiny"), tie=tie)
+        sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 3).items()}
+        path = os.path.join(tmp_path, f"ck{int(tie)}")
+        save_checkpoint_dir(path, cfg, sd, max_shard_bytes=40_000)
+        assert VVConfig.from_pretrained(path) == cfg
+        back = load_state_dict_from_dir(path)
+        assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+        assert ("lm_head.weight" in back) == (not tie)
+        assert len([f for f in os.listdir(path) if f.endswith(".safetensors")]) > 2
+        p = VibeVoiceProcessor.from_pretrained(path, tokenizer=SyntheticTokenizer(cfg.vocab))
+        assert p.speech_tok_compress_ratio == cfg.hop and p.db_normalize
+        with pytest.raises(OSError):
+            VibeVoiceProcessor.from_pretrained(path)                  # no tokenizer files, no hub access
+    j = json.load(open(os.path.join(path, "config.json")))
+    ref_json = "/root/reference/vibevoice/configs/qwen2.5_1.5b_64k.json"
+    if os.path.exists(ref_json):                                       # build container only: same key sets as the reference's own JSON
+        r = json.load(open(ref_json))
+        for sec in ("acoustic_tokenizer_config", "semantic_tokenizer_config", "diffusion_head_config"):
+            assert set(r[sec]) == set(j[sec]), (sec, set(r[sec]) ^ set(j[sec]))
+        assert set(r["decoder_config"]) <= set(j["decoder_config"]) | {"torch_dtype"}
+        assert VVConfig.from_json_dict(r) == VVConfig.preset("1.5b")
+        r7 = json.load(open(ref_json.replace("1.5b_64k", "7b_32k")))
+        assert VVConfig.from_json_dict(r7) == VVConfig.preset("7b")
+
+
 def test_no_cpu_fallback():
     from vibevoice_rocm_amd import _lib
     from vibevoice_rocm_amd.config import VVConfig
@@ -106,6 +166,41 @@ def test_processor_prompt_and_audio(tmp_path):
     p.save_audio(torch.from_numpy(x)[None], output_path=path)
     y = load_wav(path)
     assert y.shape == x.shape and np.max(np.abs(y - x)) < 1e-4 + 1 / 32768
+
+
+def test_processor_vs_reference_fixture(tmp_path):
+    """ids / masks / padded speech tensors bit-exact against the reference's own VibeVoiceProcessor.__call__ under the same stand-in
+    tokenizer (tests/golden/processor.npz, oracle/gen/make_golden.py::gen_processor; reference
+    vibevoice/processor/vibevoice_processor.py:148-229,231-289,291-389,391-444,446-494,496-616): 2- and 4-speaker scripts, a left-padded
+    batch of both, no voices, a .txt file (plain lines -> Speaker 1, empty texts dropped) and a .json file (malformed entries skipped)."""
+    from vibevoice_rocm_amd.processor import VibeVoiceProcessor, SyntheticTokenizer
+    g = load_golden("processor")
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    voices = [(a * rng.standard_normal(int(n))).astype(np.float32) for a, n in zip(g["amps"], g["lens"])]
+    s2, s4 = str(g["script2"]), str(g["script4"])
+    p = VibeVoiceProcessor(tokenizer=SyntheticTokenizer(1024))
+    kw = dict(padding=True, return_tensors="pt", return_attention_mask=True)
+    txt, js = os.path.join(tmp_path, "script.txt"), os.path.join(tmp_path, "script.json")
+    with open(txt, "w", encoding="utf-8") as f:
+        f.write(str(g["txt"]))
+    with open(js, "w", encoding="utf-8") as f:
+        f.write(str(g["json"]))
+    cases = dict(two=p(text=[s2], voice_samples=[voices[:2]], **kw), four=p(text=[s4], voice_samples=[voices], **kw),
+                 batch=p(text=[s2, s4], voice_samples=[voices[:2], voices], **kw), novoice=p(text=s2, **kw),
+                 txtfile=p(text=[txt], voice_samples=[voices[:3]], **kw), jsonfile=p(text=[js], voice_samples=[voices[:2]], **kw))
+    for tag, out in cases.items():
+        for k in ("input_ids", "attention_mask", "speech_input_mask"):
+            assert out[k].dtype == {"input_ids": torch.long, "attention_mask": torch.long, "speech_input_mask": torch.bool}[k]
+            assert np.array_equal(out[k].numpy(), g[f"{tag}_{k}"]), (tag, k)
+        if f"{tag}_speech_tensors" in g:
+            assert out["speech_tensors"].dtype == torch.float32 and out["speech_masks"].dtype == torch.bool
+            assert np.array_equal(out["speech_tensors"].numpy(), g[f"{tag}_speech_tensors"]), tag
+            assert np.array_equal(out["speech_masks"].numpy(), g[f"{tag}_speech_masks"]), tag
+        else:
+            assert out["speech_tensors"] is None and out["speech_masks"] is None
+        assert repr(out["parsed_scripts"]) == str(g[f"{tag}_parsed"]), tag
+        assert repr(out["all_speakers_list"]) == str(g[f"{tag}_speakers"]), tag
+    assert float(np.abs(g["four_speech_tensors"][2]).max()) <= 1.0 and voices[2].std() > 1.0      # the anti-clip branch was exercised
 
 
 def test_streamer_threaded():

@@ -1,6 +1,7 @@
 """The CPU oracle (oracle/vv_oracle.py) against fixtures captured from the reference's own modules
 (oracle/gen/make_golden.py).  CPU only.  Tolerances: fp32, different summation order only."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, rel_rms
@@ -149,3 +150,35 @@ def test_generate_loop_trace(tiny_cfg, tiny_weights):
         assert rel_rms(r["sem"].numpy(), g["sem"][i]) < 5e-4, i
     for i in range(g["next_embeds"].shape[0]):
         assert rel_rms(res.trace[i]["next_embeds"].numpy(), g["next_embeds"][i]) < 5e-4, i
+
+
+@pytest.mark.parametrize("preset", ["tiny", "mid"])
+def test_oracle_vs_reference_bf16_run(preset):
+    """tests/golden/sample_bf16_*.npz: the reference's head / sample_speech_tokens run in bf16 on the CPU, and the same model in fp32
+    on the same bf16-representable weights.  (1) the fp32 run pins the oracle once more (a second weight set, 10 and 20 steps);
+    (2) the oracle's `bf16_t` option - t cast to bf16 before the sinusoid, the sinusoid cast back (modeling_vibevoice_inference.py:703,
+    modular_vibevoice_diffusion_head.py:88) - is what moves fp32 arithmetic onto the reference's bf16 results; what remains is the
+    reference's own bf16 rounding noise, which calibrates the bf16 tolerance of the GPU tests (measured here: 6e-3 .. 1e-2)."""
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.synth import synth_state_dict
+    cfg = VVConfig.preset(preset)
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16).float() for k, v in synth_state_dict(cfg, 1234).items()}
+    g = load_golden(f"sample_bf16_{preset}")
+    c, nc, noise = (torch.from_numpy(g[k]) for k in ("cond", "ncond", "noise"))
+    x, c3 = torch.from_numpy(g["x"]), torch.from_numpy(g["cond3"])
+    for t in (999, 500, 50):
+        tt = torch.full((3,), float(t))
+        e32 = rel_rms(O.head_forward(sd, cfg.as_dict(), x, tt, c3).numpy(), g[f"head_fp32_t{t}"])
+        eq = rel_rms(O.head_forward(sd, cfg.as_dict(), x, tt, c3, bf16_t=True).numpy(), g[f"head_bf16_t{t}"])
+        floor = rel_rms(g[f"head_fp32_t{t}"], g[f"head_bf16_t{t}"])
+        assert e32 < 2e-6, f"head t={t}: oracle vs reference fp32 {e32:.3e}"
+        assert eq < 1.2e-2, f"head t={t}: oracle(bf16_t) vs reference bf16 {eq:.3e} (reference fp32 vs bf16 {floor:.3e})"
+    # t = 999 rounds to 1000 in bf16: without the rounding the fp32 arithmetic is several times further from the bf16 run
+    assert rel_rms(g["head_fp32_t999"], g["head_bf16_t999"]) > 3 * rel_rms(
+        O.head_forward(sd, cfg.as_dict(), x, torch.full((3,), 999.0), c3, bf16_t=True).numpy(), g["head_bf16_t999"])
+    for n in (10, 20):
+        for cs in (1.3, 2.0):
+            e32 = rel_rms(O.sample_speech_tokens(sd, cfg.as_dict(), c, nc, noise, cs, n).numpy(), g[f"latent_fp32_n{n}_cfg{cs}"])
+            eq = rel_rms(O.sample_speech_tokens(sd, cfg.as_dict(), c, nc, noise, cs, n, bf16_t=True).numpy(), g[f"latent_bf16_n{n}_cfg{cs}"])
+            assert e32 < 2e-6, f"n={n} cfg={cs}: oracle vs reference fp32 {e32:.3e}"
+            assert eq < 1.5e-2, f"n={n} cfg={cs}: oracle(bf16_t) vs reference bf16 {eq:.3e}"

@@ -92,7 +92,9 @@ class VVConfig:
             kv_heads=d["num_key_value_heads"], head_dim=d.get("head_dim") or d["hidden_size"] // heads,
             vocab=d["vocab_size"], rope_theta=float(d.get("rope_theta", 10000.0)),
             rms_eps=float(d.get("rms_norm_eps", 1e-6)), max_pos=d.get("max_position_embeddings", 32768),
-            tie=bool(d.get("tie_word_embeddings", j.get("tie_word_embeddings", False))),
+            # the inference class ties on the TOP-LEVEL key (modeling_vibevoice_inference.py:119-128), which the converter writes from
+            # decoder_config's (scripts/convert_nnscaler_checkpoint_to_transformers.py:46-50); the in-repo init JSONs carry only the latter
+            tie=bool(j["tie_word_embeddings"] if "tie_word_embeddings" in j else d.get("tie_word_embeddings", False)),
             head_hidden=h["hidden_size"], head_ffn=int(h["hidden_size"] * h.get("head_ffn_ratio", 3.0)),
             head_layers=h.get("head_layers", 4), latent=h.get("latent_size", 64),
             head_eps=float(h.get("rms_norm_eps", 1e-5)), ddpm_steps=h.get("ddpm_num_steps", 1000),

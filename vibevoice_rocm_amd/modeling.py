@@ -53,6 +53,54 @@ def load_state_dict_from_dir(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
+def save_checkpoint_dir(path: str, config: VVConfig, state_dict: Dict[str, torch.Tensor], max_shard_bytes: int = 2 * 10 ** 9,
+                        language_model_pretrained_name: str = "Qwen/Qwen2.5-1.5B") -> None:
+    """Write a checkpoint directory in the layout the reference's converter produces
+    (vibevoice/scripts/convert_nnscaler_checkpoint_to_transformers.py:92-123): `config.json` in the reference's schema (incl. the
+    `vibepod_*` model_type keys of vibevoice/configs/*.json), `preprocessor_config.json`, and safetensors shards of at most
+    `max_shard_bytes` with `model.safetensors.index.json` (a single `model.safetensors` when everything fits one shard).
+    Tied checkpoints carry no `lm_head.weight` (HF save_pretrained drops the alias)."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    j = config.to_reference_json()
+    j["model_type"] = "vibepod"
+    j["acoustic_tokenizer_config"]["model_type"] = "vibepod_acoustic_tokenizer"
+    j["semantic_tokenizer_config"]["model_type"] = "vibepod_semantic_tokenizer"
+    j["diffusion_head_config"]["model_type"] = "vibepod_diffusion_head"
+    j["torch_dtype"] = j["decoder_config"]["torch_dtype"] = "bfloat16"
+    j["tie_word_embeddings"] = bool(config.tie)             # the converter passes it to VibeVoiceConfig (:46-50)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(j, f, indent=2, sort_keys=True)
+    with open(os.path.join(path, "preprocessor_config.json"), "w") as f:
+        json.dump({"processor_class": "VibeVoiceProcessor", "speech_tok_compress_ratio": config.hop, "db_normalize": True,
+                   "audio_processor": {"feature_extractor_type": "VibeVoiceTokenizerProcessor", "sampling_rate": 24000,
+                                       "normalize_audio": True, "target_dB_FS": -25, "eps": 1e-6},
+                   "language_model_pretrained_name": language_model_pretrained_name}, f, indent=2)
+    names = [k for k in state_dict if not (config.tie and k == "lm_head.weight")]
+    shards, cur, cur_bytes = [], {}, 0
+    for k in names:
+        t = state_dict[k].detach().cpu().contiguous()
+        nb = t.numel() * t.element_size()
+        if cur and cur_bytes + nb > max_shard_bytes:
+            shards.append(cur)
+            cur, cur_bytes = {}, 0
+        cur[k] = t
+        cur_bytes += nb
+    shards.append(cur)
+    if len(shards) == 1:
+        save_file(shards[0], os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+        return
+    weight_map, total = {}, 0
+    for i, sh in enumerate(shards):
+        fn = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+        save_file(sh, os.path.join(path, fn), metadata={"format": "pt"})
+        for k, t in sh.items():
+            weight_map[k] = fn
+            total += t.numel() * t.element_size()
+    with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
+        json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=2)
+
+
 def _make_sampler(gen_cfg: dict):
     """do_sample path (modeling_vibevoice_inference.py:491-494): softmax over the constrained logits + multinomial, with the
     HF warpers the reference's callers configure (temperature, top_k, top_p; main.py:1187-1196) applied in HF order.

@@ -115,6 +115,49 @@ class VibeVoiceProcessor:
             parsed = [(i - 1, t) for i, t in parsed]
         return parsed
 
+    @staticmethod
+    def _convert_json_to_script(json_file: str) -> str:
+        """[{"speaker": "1", "text": "..."}, ...] -> "Speaker 1: ..." lines; malformed entries are skipped (:496-541)."""
+        import json
+        with open(json_file, "r", encoding="utf-8") as f:
+            data = json.load(f)
+        if not isinstance(data, list):
+            raise ValueError("JSON file must contain a list of speaker entries")
+        lines = []
+        for item in data:
+            if not isinstance(item, dict) or item.get("speaker") is None or item.get("text") is None:
+                continue
+            try:
+                speaker_id = int(item["speaker"])
+            except (ValueError, TypeError):
+                continue
+            text = item["text"].strip()
+            if text:
+                lines.append(f"Speaker {speaker_id}: {text}")
+        if not lines:
+            raise ValueError("No valid entries found in JSON file")
+        return "\n".join(lines)
+
+    @staticmethod
+    def _convert_text_to_script(text_file: str) -> str:
+        """"Speaker X: text" lines are kept, plain lines go to Speaker 1, empty lines / empty texts are dropped (:543-580)."""
+        with open(text_file, "r", encoding="utf-8") as f:
+            raw = f.readlines()
+        lines = []
+        for line in raw:
+            line = line.strip()
+            if not line:
+                continue
+            m = re.match(r"^Speaker\s+(\d+)\s*:\s*(.*)$", line, re.IGNORECASE)
+            if m:
+                if m.group(2).strip():
+                    lines.append(f"Speaker {int(m.group(1))}: {m.group(2).strip()}")
+            else:
+                lines.append(f"Speaker 1: {line}")
+        if not lines:
+            raise ValueError("No valid content found in text file")
+        return "\n".join(lines)
+
     def _create_voice_prompt(self, speaker_samples):
         tok = self.tokenizer
         tokens = tok.encode(" Voice input:\n", add_special_tokens=False)
@@ -132,9 +175,12 @@ class VibeVoiceProcessor:
         return tokens, speech_inputs, masks
 
     def _process_single(self, text: str, voice_samples=None) -> Dict[str, Any]:
-        if isinstance(text, str) and text.endswith(".txt") and os.path.exists(text):
-            with open(text) as f:
-                text = f.read()
+        if not isinstance(text, str):
+            raise ValueError(f"Could not process input text: {text}")
+        if text.endswith(".json") and os.path.exists(text):                  # :242-244
+            text = self._convert_json_to_script(text)
+        elif text.endswith(".txt") and os.path.exists(text):
+            text = self._convert_text_to_script(text)
         parsed = self._parse_script(text)
         speakers = list(set(s for s, _ in parsed))
         tok = self.tokenizer
