@@ -256,11 +256,14 @@ class VibeVoiceForConditionalGenerationInference:
         speech_noise = kwargs.get("speech_noise")            # extension: (std_noise [S], eps_noise [S, F, 64])
         sde_noise = kwargs.get("sde_noise")                  # extension: injected variance noise of the SDE solver [F, n_steps, latent]
         input_ids = torch.as_tensor(input_ids)
+        in_dev = input_ids.device                            # callers may hand over device tensors (the reference moves them itself, modeling_vibevoice_inference.py:288,305-307)
+        input_ids = input_ids.cpu()                          # ids / masks drive host-side bookkeeping only
         if input_ids.dim() == 1:
             input_ids = input_ids[None]
         B, Lp = input_ids.shape
-        if attention_mask is None:
-            attention_mask = torch.ones_like(input_ids)
+        attention_mask = torch.ones_like(input_ids) if attention_mask is None else torch.as_tensor(attention_mask).cpu()
+        if speech_input_mask is not None:
+            speech_input_mask = torch.as_tensor(speech_input_mask).cpu()
         special = dict(speech_start=tokenizer.speech_start_id, speech_end=tokenizer.speech_end_id,
                        speech_diffusion=tokenizer.speech_diffusion_id, eos=tokenizer.eos_token_id,
                        bos=getattr(tokenizer, "bos_token_id", None))
@@ -296,7 +299,7 @@ class VibeVoiceForConditionalGenerationInference:
         seq_t = torch.full((B, mx), int(pad_id), dtype=torch.long)
         for b, s in enumerate(seqs):
             seq_t[b, : s.shape[0]] = s
-        return VibeVoiceGenerationOutput(sequences=seq_t, speech_outputs=audios if return_speech else None,
+        return VibeVoiceGenerationOutput(sequences=seq_t.to(in_dev), speech_outputs=audios if return_speech else None,
                                          reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
 
     def _generate_one(self, ids: torch.Tensor, sp_mask, conn, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
