@@ -182,6 +182,14 @@ size_t vv_llm_ws_bytes(const vv_llm* m, int R);
  * pass; modeling_vibevoice_inference.py:478-480 and :581-583) and the prompt prefill (R = L0; :478 at step 0). */
 int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
                    const int* cache_rows, float* out, int64_t ldo, void* ws, vv_stream_t stream);
+/* out == NULL: the final RMSNorm is left to the caller; the un-normalised last hidden rows then stay at the START of ws as [R, hidden] fp32.
+ * vv_llm_tail finishes a decode step in one launch: out[R, hidden] = final RMSNorm(h) (the {condition, negative condition} of the
+ * diffusion head), logits[nv] = w_valid[nv, hidden] . out[0] (the constrained vocabulary rows of lm_head, VibeVoiceTokenConstraintProcessor
+ * modeling_vibevoice_inference.py:53-66), token = ids[argmax] (first maximum in ascending id order) unless *forced_token >= 0, and the
+ * position bookkeeping of vv_advance_lens (lens == NULL: skipped). */
+int vv_llm_tail(const vv_llm* m, const float* h, int64_t ldh, int R, float* out, int64_t ldo, const void* w_valid, int nv, const int* ids,
+                float* logits_out, int* token_out, const int* forced_token, int* lens, int tok_start, int tok_diffusion, int* frame_counter,
+                vv_stream_t stream);
 
 typedef struct vv_head_layer {
   const float* norm_w;
@@ -202,6 +210,9 @@ typedef struct vv_head {
   const void* final_adaln;   /* [2D, D]: shift | scale */
   const void* final_linear;  /* [latent, D] */
   const vv_head_layer* layer; /* (host) array */
+  const float* fused_g;      /* optional [D + latent, D] fp32: [noisy_proj x final_linear ; final_linear].  When set, vv_head_sample runs a solver-step
+                                boundary (FinalLayer + CFG + DPM-Solver++ update + next noisy_images_proj: all linear in the modulated hidden state) as
+                                ONE GEMV over it with the solver as epilogue; NULL keeps the three-launch form */
 } vv_head;
 
 typedef struct vv_dpm_coef { float alpha_s, sigma_s, cx, cd, rinv; int order; float cn; /* variance-noise coefficient: 0 for the ODE solver, sigma_t sqrt(1 - e^-2h) for sde-dpmsolver++ */ } vv_dpm_coef;

@@ -57,7 +57,7 @@ class HeadLayer(C.Structure):
 class Head(C.Structure):
     _fields_ = [("wdt", C.c_int), ("D", C.c_int), ("ffn", C.c_int), ("layers", C.c_int), ("latent", C.c_int),
                 ("cond_dim", C.c_int), ("eps", C.c_float), ("flags", C.c_int), ("noisy_proj", vp), ("cond_proj", vp), ("final_adaln", vp),
-                ("final_linear", vp), ("layer", C.POINTER(HeadLayer))]
+                ("final_linear", vp), ("layer", C.POINTER(HeadLayer)), ("fused_g", vp)]
 
 
 class DpmCoef(C.Structure):
@@ -90,7 +90,7 @@ class ProfEntry(C.Structure):
                 ("total_ms", C.c_double)]
 
 
-_STRUCTS = dict(vv_prof_entry=ProfEntry, vv_lin_args=LinArgs, vv_kv=KV, vv_llm_layer=LlmLayer, vv_llm=Llm, vv_head_layer=HeadLayer, vv_head=Head,
+_STRUCTS = dict(vv_w8=W8, vv_prof_entry=ProfEntry, vv_lin_args=LinArgs, vv_kv=KV, vv_llm_layer=LlmLayer, vv_llm=Llm, vv_head_layer=HeadLayer, vv_head=Head,
                 vv_dpm_coef=DpmCoef, vv_block=Block, vv_conv=Conv, vv_convnet=ConvNet, vv_connector=Connector)
 
 # name -> (restype, argtypes); every symbol include/vv_hip.h declares
@@ -122,6 +122,7 @@ PROTOTYPES = {
     "vv_advance_lens": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "vv_llm_ws_bytes": (C.c_size_t, [C.POINTER(Llm), C.c_int]),
     "vv_llm_forward": (C.c_int, [C.POINTER(Llm), C.POINTER(KV), vp, i64, C.c_int, vp, vp, vp, i64, vp, vp]),
+    "vv_llm_tail": (C.c_int, [C.POINTER(Llm), vp, i64, C.c_int, vp, i64, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vv_head_ws_bytes": (C.c_size_t, [C.POINTER(Head), C.c_int]),
     "vv_head_sample": (C.c_int, [C.POINTER(Head), vp, i64, vp, vp, C.POINTER(DpmCoef), C.c_int, C.c_float, vp, vp, vp, vp]),
     "vv_head_forward": (C.c_int, [C.POINTER(Head), vp, vp, vp, C.c_int, vp, vp, vp]),

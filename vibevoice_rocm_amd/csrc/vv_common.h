@@ -44,6 +44,13 @@ static inline void vv_chain_set_dbg_mode(int) {}
 static inline void vv_chain_set_dbg(int, int) {}
 static inline void vv_chain_set_head(int) {}
 #endif
+// vv_fused.hip
+int vv_head_init_fused(const vv_head* h, const float* noise, float* Xs, float* Ms, float* h0, int64_t ldh, hipStream_t s);
+bool vv_head_boundary_supported(const vv_head* h);
+int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
+                           const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s);
+struct vv_conv_ctx_item { float* pad; float* state; int ctx, T, C; };
+int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStream_t s);   // scatter 0: pad[0:ctx] <- state; 1: state <- pad[T : T + ctx]
 int vv_block1d_init();                                            // vv_block1d.hip
 int vv_launch_block1d(const vv_block& B, int wdt, const float* x, float* out, int T, int C, float eps, hipStream_t s);   // 1 launched, 0 not covered
 void vv_block1d_set_fused(int on);

@@ -45,8 +45,22 @@ __device__ __forceinline__ void unpack8_f8(const u32x4 v, float (&o)[8]) {
 // epilogue operands (bias / adaLN gate / residual) of one output: their addresses are known before the dot product is, so
 // they are loaded one row group ahead, in front of the weight loads that follow them in the queue (loads return in order: an
 // operand load issued at epilogue time would sit behind two row groups of prefetched weights)
-struct EpiOp { float b, g, r, s, s2; };   // bias, gate, residual, fp8 row scales
+struct EpiOp { float b, g, r, s, s2; };   // bias, gate, residual, fp8 row scales (raw loads; absent operands are ignored at use)
 __device__ __forceinline__ EpiOp epi_load(const vv_lin_args& a, int m, int n) {
+  // straight-line and use-free: an absent operand reads x[0] (always a valid address), the values are only looked at in epi_pre.
+  // With a select per operand here the compiler waited for each dword right away - draining every load issued before it - and a
+  // uniform branch per operand cut the issue sequence into blocks it then reordered.
+  EpiOp e;
+  const bool f8s = a.wdt == VV_FP8, f8d = f8s && a.w2;
+  const float* pb = a.bias ? a.bias + n : a.x;
+  const float* pg = a.gate ? a.gate + (a.gate_ld ? (int64_t)m * a.gate_ld + n : (int64_t)n) : a.x;
+  const float* pr = a.res ? a.res + (int64_t)m * a.ldres + n : a.x;
+  const float* ps = f8s ? a.wscale + n : a.x;
+  const float* ps2 = f8d ? a.w2scale + n : a.x;
+  e.b = *pb; e.g = *pg; e.r = *pr; e.s = *ps; e.s2 = *ps2;
+  return e;
+}
+__device__ __forceinline__ EpiOp epi_load_cond(const vv_lin_args& a, int m, int n) {   // one uniform branch per operand (owner lanes only)
   EpiOp e;
   e.b = a.bias ? a.bias[n] : 0.f;
   e.g = a.gate ? (a.gate_ld ? a.gate[(int64_t)m * a.gate_ld + n] : a.gate[n]) : 1.f;
@@ -56,8 +70,8 @@ __device__ __forceinline__ EpiOp epi_load(const vv_lin_args& a, int m, int n) {
   return e;
 }
 __device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, float v, float v2, const EpiOp& e) {
-  v = v * e.s + e.b;                             // e.s = 1 unless the weights are fp8 codes with a row scale
-  v2 *= e.s2;
+  if (a.wdt == VV_FP8) { v *= e.s; if (a.w2) v2 *= e.s2; }      // fp8 codes carry a row scale
+  if (a.bias) v += e.b;
   if (a.act == VV_ACT_GELU) v = gelu1(v);
   else if (a.act == VV_ACT_SWIGLU) v = silu1(v) * v2;
   if (a.gate) v *= e.g;
@@ -66,15 +80,18 @@ __device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, floa
 }
 
 int g_blocks_override = 0;   // tuning hook (vv_tune)
+int g_opt = 13;              // tuning hook "gemv_opt": bit 0 / 1 = batched prologue for RMSNorm / no prologue, bit 2 = straight-line epilogue-operand loads, bit 3 = block-staged RMSNorm prologue (KSPLIT == 1)
 int g_long_cap = 512;        // persistent blocks for K-split launches with K > 6144 (tuning hook)
 int g_long_ku = 5;           // K units per wave allowed for rows longer than 12 units (tuning hook: 3 -> 8 waves split K)
 
 template <int M, bool DUAL, int KSPLIT, int KU, int RW, bool F8>
-__global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_kernel(const vv_lin_args a, const int n_groups) {
-  constexpr int NW = (KSPLIT == 1) ? 4 : KSPLIT;     // waves per block
+__global__ __launch_bounds__(KSPLIT == 1 ? 512 : 64 * KSPLIT) void gemv_stream_kernel(const vv_lin_args a, const int n_groups, const int opt) {
+  constexpr int NW = (KSPLIT == 1) ? 8 : KSPLIT;     // waves per block (KSPLIT == 1: at most; the launcher picks 3 .. 8 so that the row groups divide evenly)
   __shared__ float red[NW * M];
   __shared__ float part[2][NW][RW * M * 2];
+  __shared__ __attribute__((aligned(16))) float xs[KSPLIT == 1 ? M * KU * 512 : 4];   // block-staged prologue result (KSPLIT == 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwv = (KSPLIT == 1) ? (int)(blockDim.x >> 6) : KSPLIT;
   const int K = a.k, N = a.n, mr = a.m;          // mr <= M real rows
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(a.w);
   const bf16_t* __restrict__ W2 = reinterpret_cast<const bf16_t*>(a.w2);
@@ -92,27 +109,31 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
   const bool reused = (a.flags & VV_LIN_W_REUSED) != 0;
   constexpr bool f8 = F8;                        // weight-only fp8 is its own instantiation: the bf16 kernels carry none of it
   // the first row group's weight loads are issued before the activation prologue so both latencies overlap
-  const int gstride = (KSPLIT == 1) ? gridDim.x * 4 : gridDim.x;
-  int g = (KSPLIT == 1) ? blockIdx.x * 4 + wave : blockIdx.x;
+  const int gstride = (KSPLIT == 1) ? gridDim.x * nwv : gridDim.x;
+  int g = (KSPLIT == 1) ? blockIdx.x * nwv + wave : blockIdx.x;
   u32x4 cur[RW][KU], cur2[DUAL ? RW : 1][KU];
   u32x4 nxt[RW][KU], nxt2[DUAL ? RW : 1][KU];
   auto issue = [&](u32x4 (&b)[RW][KU], u32x4 (&b2)[DUAL ? RW : 1][KU], int grp) {
+    // a group past the end (the unconditional second issue of a wave that owns a single group) degenerates to one 16-byte
+    // line per instruction: every lane reads element 0 of the matrix
+    const bool live = grp < n_groups;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const int n = min(grp * RW + r, N - 1);
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
+        const int64_t off = live ? (int64_t)n * K + koff[u] : 0;
         if (f8) {                // e4m3fn bytes: this lane's 8 weights are 8 bytes
-          const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(a.w) + (int64_t)n * K + koff[u]));
+          const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(a.w) + off));
           b[r][u].x = t.x; b[r][u].y = t.y;
           if (DUAL) {
-            const u32x2 t2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(a.w2) + (int64_t)n * K + koff[u]));
+            const u32x2 t2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(a.w2) + off));
             b2[r][u].x = t2.x; b2[r][u].y = t2.y;
           }
           continue;
         }
-        const u32x4* p1 = reinterpret_cast<const u32x4*>(W + (int64_t)n * K + koff[u]);
-        const u32x4* p2 = reinterpret_cast<const u32x4*>(W2 + (int64_t)n * K + koff[u]);
+        const u32x4* p1 = reinterpret_cast<const u32x4*>(W + off);
+        const u32x4* p2 = reinterpret_cast<const u32x4*>(W2 + off);
         if (reused) {            // weights re-read by the next solver step: leave them in L2 / Infinity Cache
           b[r][u] = *p1;
           if (DUAL) b2[r][u] = *p2;
@@ -130,18 +151,201 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
   const bool has_eo = a.bias || a.gate || a.res || a.wdt == VV_FP8;
   const int eid = (KSPLIT == 1) ? lane : tid;
   EpiOp eo_cur[NE], eo_nxt[NE];
+  const int eo_id = eid < RW * M ? eid : 0;       // lanes that own no output fetch output 0's operands: no divergent branch around the loads
+  const int eo_r = eo_id / M, eo_m = (eo_id - eo_r * M) < mr ? (eo_id - eo_r * M) : mr - 1;
   auto load_eo = [&](EpiOp (&e)[NE], int grp) {
-    if (!has_eo || grp >= n_groups) return;
-    if (eid < RW * M) {
-      const int r = eid / M, m = eid - r * M;
-      e[0] = epi_load(a, m < mr ? m : mr - 1, min(grp * RW + r, N - 1));
-    }
+    if (!has_eo) return;
+    if (opt & 4) { e[0] = epi_load(a, eo_m, min((grp < n_groups ? grp : n_groups - 1) * RW + eo_r, N - 1)); return; }
+    if (grp < n_groups && eid < RW * M) e[0] = epi_load_cond(a, eo_m, min(grp * RW + eo_r, N - 1));
   };
 #pragma unroll
   for (int i = 0; i < NE; ++i) { eo_cur[i].b = 0.f; eo_cur[i].g = 1.f; eo_cur[i].r = 0.f; eo_cur[i].s = 1.f; eo_cur[i].s2 = 1.f; eo_nxt[i] = eo_cur[i]; }
+  float xr[M][KU][8];
+  // Activation side.  BATCHED (the per-frame shapes: M * KU <= 8, no SiLU prologue): every load the prologue needs - x rows, norm
+  // weight, adaLN shift / scale - is issued in ONE batch AHEAD of the weight loads.  Loads return in order: these are L2 hits and
+  // come back first, so the statistics and the normalisation run while the first two row groups of weights are still in flight.
+  // (Issued behind the weights, and unit by unit with a full wait each, the prologue was 6-12 dependent round trips that only
+  // started once the first weights had landed: +2 us on every kernel with a prologue, +4 us on the dual one.)
+  // the SwiGLU (dual) kernels take the block-staged prologue, the others the per-wave batched one: one fast path per instantiation
+  // keeps the register allocation of each kernel at what its own path needs
+  constexpr bool CAN_STAGE = KSPLIT == 1 && DUAL;
+  constexpr bool BATCHED = (M * KU <= 8) && !CAN_STAGE;
+  // adaLN-modulated rows on a non-dual kernel (the head's 64-row final linear) keep the legacy path: the batch would pin 96 more registers
+  const bool batched = BATCHED && ((a.pro == VV_PRO_RMSNORM && !a.mod_scale && (opt & 1)) || (a.pro == VV_PRO_NONE && (opt & 2)));
+  bool staged = false;
+  if constexpr (CAN_STAGE) staged = a.pro == VV_PRO_RMSNORM && (opt & 8);
+  if (CAN_STAGE && staged) {
+    // Prologue ONCE PER BLOCK (KSPLIT == 1, RMSNorm): thread t owns the 4-element chunks t, t + T, ... of every row; x, the norm weight
+    // and the adaLN shift / scale chunks are requested first, then the first two row groups of weights; statistics through LDS, the
+    // normalised rows land in LDS and every lane picks up its k slices from there.  With the prologue per WAVE every one of ~2000
+    // waves pulled x, norm weight and modulation (42 KB for the head's SwiGLU GEMV: 86 MB against 28 MB of weights) through L2 at
+    // the moment the weight stream saturates the fabric: the median wave saw its activations 4 us after entry (tools/gemv_lab.cpp).
+    const int T = nwv * 64;
+    constexpr int NCH = (KU * 128 + 191) / 192;     // 4-element chunks per thread per row (blocks have >= 3 waves)
+    const bool has_nw = a.norm_w != nullptr, has_mod = a.mod_scale != nullptr;
+    float4 xv[M][NCH], nv[NCH], sv[M][NCH], cv[M][NCH];
+    const int nchunks = K >> 2;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = tid + c * T;
+      const int kk = ch < nchunks ? ch * 4 : 0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) xv[m][c] = *reinterpret_cast<const float4*>(a.x + (int64_t)(m < mr ? m : mr - 1) * a.ldx + kk);
+      if (has_nw) nv[c] = *reinterpret_cast<const float4*>(a.norm_w + kk);
+      if (has_mod) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const int64_t mo = (int64_t)(m < mr ? m : mr - 1) * a.ld_mod + kk;
+          sv[m][c] = *reinterpret_cast<const float4*>(a.mod_shift + mo);
+          cv[m][c] = *reinterpret_cast<const float4*>(a.mod_scale + mo);
+        }
+      }
+    }
+    load_eo(eo_cur, g);
+    issue(cur, cur2, g);
+    load_eo(eo_nxt, g + gstride);
+    issue(nxt, nxt2, g + gstride);
+    __builtin_amdgcn_sched_barrier(0);
+#define VV_FENCE4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) VV_FENCE4(xv[m][c]);
+      if (has_nw) VV_FENCE4(nv[c]);
+      if (has_mod) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) { VV_FENCE4(sv[m][c]); VV_FENCE4(cv[m][c]); }
+      }
+    }
+#undef VV_FENCE4
+    float ss[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float4 v = xv[m][c];
+        s1 += (tid + c * T < nchunks) ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+      }
+      ss[m] = wsum(s1);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) red[wave * M + m] = ss[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float tot = 0.f;
+      for (int w4 = 0; w4 < nwv; ++w4) tot += red[w4 * M + m];      // fixed order: deterministic
+      const float rstd = rsqrtf(tot / (float)K + a.eps);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = tid + c * T;
+        float4 v = xv[m][c];
+        v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
+        if (has_nw) { v.x *= nv[c].x; v.y *= nv[c].y; v.z *= nv[c].z; v.w *= nv[c].w; }
+        if (has_mod) {
+          v.x = v.x * (1.0f + cv[m][c].x) + sv[m][c].x; v.y = v.y * (1.0f + cv[m][c].y) + sv[m][c].y;
+          v.z = v.z * (1.0f + cv[m][c].z) + sv[m][c].z; v.w = v.w * (1.0f + cv[m][c].w) + sv[m][c].w;
+        }
+        if (ch < KU * 128) *reinterpret_cast<float4*>(&xs[(m * KU * 128 + ch) * 4]) = ch < nchunks ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const float4 p = *reinterpret_cast<const float4*>(&xs[m * KU * 512 + u * 512 + lane * 8]);
+        const float4 q = *reinterpret_cast<const float4*>(&xs[m * KU * 512 + u * 512 + lane * 8 + 4]);
+        xr[m][u][0] = p.x; xr[m][u][1] = p.y; xr[m][u][2] = p.z; xr[m][u][3] = p.w;
+        xr[m][u][4] = q.x; xr[m][u][5] = q.y; xr[m][u][6] = q.z; xr[m][u][7] = q.w;
+      }
+  } else if (BATCHED && batched) {
+    float4 xa[M][KU], xb[M][KU], na[KU], nb[KU];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float* xrow = a.x + (int64_t)(m < mr ? m : mr - 1) * a.ldx;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        xa[m][u] = *reinterpret_cast<const float4*>(xrow + koff[u]);
+        xb[m][u] = *reinterpret_cast<const float4*>(xrow + koff[u] + 4);
+      }
+    }
+    const bool rms = a.pro == VV_PRO_RMSNORM;
+    const bool has_nw = rms && a.norm_w;
+    if (has_nw) {
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        na[u] = *reinterpret_cast<const float4*>(a.norm_w + koff[u]);
+        nb[u] = *reinterpret_cast<const float4*>(a.norm_w + koff[u] + 4);
+      }
+    }
+    // the first two row groups go out unconditionally (a group past the end costs one 16-byte line per load instruction) so that
+    // no branch separates them from the loads above, and nothing below is scheduled ahead of them
+    load_eo(eo_cur, g);
+    issue(cur, cur2, g);
+    load_eo(eo_nxt, g + gstride);
+    issue(nxt, nxt2, g + gstride);
+    __builtin_amdgcn_sched_barrier(0);
+    // everything the prologue computes with is made opaque HERE, behind the weight loads: hipcc otherwise hoists pieces of the
+    // arithmetic (and the waits they need) into the blocks above, in front of the weight issue
+#define VV_FENCE4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) { VV_FENCE4(xa[m][u]); VV_FENCE4(xb[m][u]); }
+      if (has_nw) { VV_FENCE4(na[u]); VV_FENCE4(nb[u]); }
+    }
+#undef VV_FENCE4
+    float ss[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      ss[m] = 0.f;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const bool kv = kval[u];                         // lanes past K read a valid address and contribute zeros
+        xr[m][u][0] = kv ? xa[m][u].x : 0.f; xr[m][u][1] = kv ? xa[m][u].y : 0.f; xr[m][u][2] = kv ? xa[m][u].z : 0.f; xr[m][u][3] = kv ? xa[m][u].w : 0.f;
+        xr[m][u][4] = kv ? xb[m][u].x : 0.f; xr[m][u][5] = kv ? xb[m][u].y : 0.f; xr[m][u][6] = kv ? xb[m][u].z : 0.f; xr[m][u][7] = kv ? xb[m][u].w : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss[m] = fmaf(xr[m][u][j], xr[m][u][j], ss[m]);
+      }
+    }
+    if (rms) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) ss[m] = wsum(ss[m]);   // KSPLIT == 1: every wave holds the whole row
+      if (KSPLIT != 1) {
+        if (lane == 0) {
+#pragma unroll
+          for (int m = 0; m < M; ++m) red[wave * M + m] = ss[m];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          ss[m] = 0.f;
+#pragma unroll
+          for (int w4 = 0; w4 < nwv; ++w4) ss[m] += red[w4 * M + m];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float rstd = rsqrtf(ss[m] / (float)K + a.eps);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const float nw[8] = {na[u].x, na[u].y, na[u].z, na[u].w, nb[u].x, nb[u].y, nb[u].z, nb[u].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = xr[m][u][j] * rstd;
+            if (has_nw) v *= nw[j];
+            xr[m][u][j] = kval[u] ? v : 0.f;
+          }
+        }
+      }
+    }
+  } else {
   if (g < n_groups) { load_eo(eo_cur, g); issue(cur, cur2, g); }
   if (g + gstride < n_groups) { load_eo(eo_nxt, g + gstride); issue(nxt, nxt2, g + gstride); }   // two row groups in flight before the prologue even starts
-  float xr[M][KU][8];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const float* xrow = a.x + (int64_t)(m < mr ? m : mr - 1) * a.ldx;
@@ -171,7 +375,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
         __syncthreads();
         ss = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < NW; ++w4) ss += red[w4 * M + m];
+        for (int w4 = 0; w4 < nwv; ++w4) ss += red[w4 * M + m];
       }
       const float rstd = rsqrtf(ss / (float)K + a.eps);
 #pragma unroll
@@ -199,6 +403,8 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 256 : 64 * KSPLIT) void gemv_stream_k
         }
       }
     }
+  }
+
   }
 
   // ---- stream the weight rows ------------------------------------------------------------------------------------
@@ -285,19 +491,21 @@ void launch_rw(const vv_lin_args& a, hipStream_t s) {
   // wave-per-row layout (more blocks only add prologue copies and a ragged last round), one block per row group when the
   // block's waves split K
   const int n_groups = (a.n + RW - 1) / RW;
+  int waves = 4;
   const int work = (KSPLIT == 1) ? (n_groups + 3) / 4 : n_groups;       // blocks if each wave did exactly one group
   // K split: every block reads all of x (M x K fp32 from L2); beyond ~6K columns that traffic rivals the weights, so long
   // rows use fewer, persistent blocks (n=1536 k=8960: 10.4 us at 768 blocks, 9.1 us at 512)
   const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : (a.k > 6144 ? g_long_cap : 1024);
   int blocks = work < cap ? work : cap;
   if (g_blocks_override > 0) blocks = g_blocks_override < work ? g_blocks_override : work;
+  const int threads = KSPLIT == 1 ? 64 * waves : 64 * KSPLIT;
   if constexpr (M <= 2) {                        // fp8 weights: decode rows only
     if (a.wdt == VV_FP8) {
-      hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW, true>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
+      hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW, true>), dim3(blocks), dim3(threads), 0, s, a, n_groups, g_opt);
       return;
     }
   }
-  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW, false>), dim3(blocks), dim3(KSPLIT == 1 ? 256 : 64 * KSPLIT), 0, s, a, n_groups);
+  hipLaunchKernelGGL((gemv_stream_kernel<M, DUAL, KSPLIT, KU, RW, false>), dim3(blocks), dim3(threads), 0, s, a, n_groups, g_opt);
 }
 
 int g_small_rw = 2;           // rows per wave step for narrow non-dual matrices (tuning hook)
@@ -349,6 +557,7 @@ bool launch_m8(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
 }  // namespace
 
 void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
+void vv_gemv_stream_set_opt(int o) { g_opt = o; }
 void vv_gemv_stream_set_long(int cap, int ku) { if (cap > 0) g_long_cap = cap; if (ku > 0) g_long_ku = ku; }
 void vv_gemv_stream_set_dual_rw(int r) { g_dual_rw = r; }
 void vv_gemv_stream_set_small_rw(int r) { g_small_rw = r; }

@@ -29,7 +29,7 @@ int vv_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* vv_last_error(void) { return g_err; }
-extern "C" int vv_abi_version(void) { return 2; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments
+extern "C" int vv_abi_version(void) { return 3; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL)
 int vv_mixer_init();
 extern "C" int vv_init(void) {
   VV_TRY(vv_mixer_init());
@@ -38,6 +38,7 @@ extern "C" int vv_init(void) {
   return vv_chain_init();
 }
 void vv_gemv_stream_set_blocks(int b);
+void vv_gemv_stream_set_opt(int o);
 void vv_gemv_stream_set_long(int cap, int ku);
 void vv_gemv_stream_set_dual_rw(int r);
 void vv_gemv_stream_set_small_rw(int r);
@@ -55,6 +56,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_long_cap")) { vv_gemv_stream_set_long(value, 0); return 0; }
   if (key && !strcmp(key, "gemv_long_ku")) { vv_gemv_stream_set_long(0, value); return 0; }
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
+  if (key && !strcmp(key, "gemv_opt")) { vv_gemv_stream_set_opt(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
   if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }

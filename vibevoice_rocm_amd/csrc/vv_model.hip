@@ -54,7 +54,7 @@ extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
                               const int* cache_rows, float* out, int64_t ldo, void* ws, vv_stream_t stream) {
-  if (!m || !kv || !x || !lens || !out || !ws || !m->layer) return vv_set_error(VV_E_ARG, "vv_llm_forward: null pointer");
+  if (!m || !kv || !x || !lens || !ws || !m->layer) return vv_set_error(VV_E_ARG, "vv_llm_forward: null pointer");
   if (R <= 0) return vv_set_error(VV_E_ARG, "vv_llm_forward: R=%d", R);
   if (kv->layers != m->layers || kv->kv_heads != m->kv_heads || kv->head_dim != m->head_dim)
     return vv_set_error(VV_E_ARG, "vv_llm_forward: kv cache shape does not match the model");
@@ -66,7 +66,9 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   float* att = c.take((size_t)R * qd);
   float* act = c.take((size_t)R * m->inter);
   float* rope = c.take((size_t)R * d);
-  VV_TRY(vv_copy_rows(x, ldx, h, H, R, H, stream));
+  // layer 0 reads the input embeddings where they lie (prologue and residual operand): no copy into the workspace
+  const float* hin = x;
+  int64_t ldh = ldx;
   VV_TRY(vv_rope_table(lens, m->inv_freq, R, d, rope, stream));
   const bool prefill = (R >= VV_PREFILL_ROWS) && m->wdt == VV_BF16 && H % 16 == 0 && m->inter % 16 == 0 && qd % 16 == 0;
   void* xb = prefill ? (void*)c.take((size_t)R * (m->inter > H ? m->inter : H) / 2 + 64) : nullptr;
@@ -75,11 +77,11 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     const vv_llm_layer& L = m->layer[l];
     vv_lin_args a;
     if (prefill) {
-      VV_TRY(vv_cast_rows_bf16(h, H, R, H, VV_PRO_RMSNORM, L.ln1, m->rms_eps, xb, H, stream));
+      VV_TRY(vv_cast_rows_bf16(hin, ldh, R, H, VV_PRO_RMSNORM, L.ln1, m->rms_eps, xb, H, stream));
       a = lin_base((const float*)xb, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
       a.flags = VV_LIN_X_BF16; a.bias = L.bqkv;
     } else {
-      a = lin_base(h, H, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
+      a = lin_base(hin, ldh, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
       a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
       use_w8(a, L.q_qkv);
     }
@@ -98,8 +100,9 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
       use_w8(a, L.q_o);
     }
-    a.res = h; a.ldres = H;
+    a.res = hin; a.ldres = ldh;
     VV_TRY(vv_linear(&a, stream));
+    hin = h; ldh = H;
     if (prefill) {
       VV_TRY(vv_cast_rows_bf16(h, H, R, H, VV_PRO_RMSNORM, L.ln2, m->rms_eps, xb, H, stream));
       a = lin_base((const float*)xb, H, R, L.wgate, m->inter, H, m->wdt, act, m->inter);
@@ -124,6 +127,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     a.res = h; a.ldres = H;
     VV_TRY(vv_linear(&a, stream));
   }
+  if (!out) return 0;       // the caller runs the final norm itself (vv_llm_tail: norm + logits + token + bookkeeping in one launch)
   return vv_rmsnorm_rows(h, H, m->final_norm, m->rms_eps, R, H, out, ldo, s);
 }
 
@@ -136,7 +140,8 @@ extern "C" size_t vv_head_ws_bytes(const vv_head* h, int n_steps) {
   const size_t D = h->D;
   return al(8 * D) /*c0*/ + al(R * D) /*c*/ + (size_t)h->layers * al(R * 3 * D) + al(R * 2 * D) + al(8 * D) /*hcur*/ +
          al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + 4 * al(h->latent) /*x, x0 history: double-buffered*/ +
-         al(vv_head_chain_ws_floats(h)) /*flags + tagged hand-off buffers of the chained kernel*/;
+         al(vv_head_chain_ws_floats(h)) /*flags + tagged hand-off buffers of the chained kernel*/ +
+         al(8 * D) /*second hidden-row buffer*/ + 2 * al(D + (size_t)h->latent) /*fused solver state X, M*/;
 }
 
 // shared body: rows R (<= 8), modulation tables mod[l] [*, 3D] / modf [*, 2D] with row offset `mrow`
@@ -226,6 +231,9 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   float* xb[2] = {cv.take(h->latent), cv.take(h->latent)};       // x and x0-history are double-buffered per step
   float* mb[2] = {cv.take(h->latent), cv.take(h->latent)};
   float* chain_ws = cv.take(vv_head_chain_ws_floats(h));
+  float* hcur2 = cv.take(8 * (size_t)D);
+  float* Xs = cv.take(D + (size_t)h->latent);
+  float* Ms = cv.take(D + (size_t)h->latent);
   // step-invariant work hoisted out of the loop: cond_proj, silu(cond_proj(cond) + t_emb(t_i)), all adaLN modulations
   vv_lin_args a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
   VV_TRY(vv_linear(&a, stream));
@@ -237,6 +245,33 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   const int chained = sde_noise ? 0 : vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
   if (chained < 0) return chained;
   if (chained) return 0;
+  if (!sde_noise && vv_head_boundary_supported(h)) {
+    // one launch per step boundary: FinalLayer + CFG + DPM-Solver++ update + next noisy_images_proj as ONE GEMV over G = [P F ; F]
+    // with the solver in its epilogue (vv_fused.hip).  The hidden rows alternate between two buffers: the boundary kernel of step i
+    // reads the rows the layers of step i worked on while it writes the rows step i + 1 starts from.
+    float* hb[2] = {hcur, hcur2};
+    VV_TRY(vv_head_init_fused(h, noise, Xs, Ms, hb[0], D, s));
+    for (int i = 0; i < n_steps; ++i) {
+      float* hc = hb[i & 1];
+      for (int l = 0; l < h->layers; ++l) {
+        const vv_head_layer& L = h->layer[l];
+        const float* ml = mod[l] + (size_t)2 * i * 3 * D;
+        a = lin_base(hc, D, 2, L.wgate, h->ffn, D, h->wdt, act, h->ffn);
+        a.pro = VV_PRO_RMSNORM; a.norm_w = L.norm_w; a.eps = h->eps;
+        a.mod_shift = ml; a.mod_scale = ml + D; a.ld_mod = 3 * D;
+        a.w2 = L.wup; a.act = VV_ACT_SWIGLU; a.flags = VV_LIN_W_REUSED;
+        use_w8(a, L.q_gate, &L.q_up);
+        VV_TRY(vv_linear(&a, stream));
+        a = lin_base(act, h->ffn, 2, L.wdown, D, h->ffn, h->wdt, hc, D);
+        a.gate = ml + 2 * D; a.gate_ld = 3 * D; a.res = hc; a.ldres = D; a.flags = VV_LIN_W_REUSED;
+        use_w8(a, L.q_down);
+        VV_TRY(vv_linear(&a, stream));
+      }
+      const float* mf = modf + (size_t)2 * i * 2 * D;
+      VV_TRY(vv_head_boundary_fused(h, hc, D, mf, mf + D, 2 * D, cfg_scale, &coef[i], Xs, Ms, hb[(i + 1) & 1], D, latent_out, s));
+    }
+    return 0;
+  }
   for (int i = 0; i <= n_steps; ++i) {
     // step boundary: solver update of the previous step's v (none before step 0) fused with this step's noisy_images_proj
     const float* xin = (i == 0) ? noise : xb[(i - 1) & 1];
@@ -278,11 +313,32 @@ static void convnet_sizes(const vv_convnet* net, int64_t t_in, int decoder, size
   *hid_elems = hmax + 64;
 }
 
+// streaming nets (every conv carries a state buffer): each conv's padded input [ctx + T, cin] gets a region of its own, so the left
+// contexts of ALL convs can be put in place by one launch before the first conv runs and collected by one launch after the last
+static bool convnet_streaming(const vv_convnet* net) {
+  for (int i = 0; i <= net->n_stages; ++i) {
+    const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
+    if (conv_ctx_of(cv) > 0 && !cv.state) return false;
+  }
+  return true;
+}
+static size_t convnet_pad_floats(const vv_convnet* net, int64_t t_in, size_t* offs /* [n_stages + 1] or null */) {
+  size_t tot = 0;
+  int64_t T = t_in;
+  for (int i = 0; i <= net->n_stages; ++i) {
+    const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
+    if (offs) offs[i] = tot;
+    tot += (((size_t)(T + conv_ctx_of(cv) + 2) * cv.cin) + 63) & ~(size_t)63;
+    if (cv.transposed) T = T * cv.stride; else T = (T + cv.stride - 1) / cv.stride;
+  }
+  return tot;
+}
+
 extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int decoder) {
   if (!net || t_in <= 0) return 0;
   size_t a, h;
   convnet_sizes(net, t_in, decoder, &a, &h);
-  return 2 * al(a) + al(h);
+  return 2 * al(a) + al(h) + (convnet_streaming(net) ? al(convnet_pad_floats(net, t_in, nullptr)) : 0);
 }
 
 // Runs the stage's blocks on the ping-pong buffers cur / other.  The LAST block writes its result `nctx` rows into a buffer so
@@ -290,23 +346,24 @@ extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int d
 // dead input buffer is the only one free, so the result goes there, shifted.  Fused block (one launch reads its input while
 // other row tiles already write): the result must not overlap the input; `other` is free (no mixer output) and takes it.
 static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*& cur, float*& other, float* hid,
-                      int nctx, float** pad_out, vv_stream_t stream) {
+                      int nctx, float** pad_out, vv_stream_t stream, float* next_pad = nullptr) {
+  // next_pad (streaming nets): the next conv's own padded-input region; the stage result goes to next_pad + nctx rows
   const int nb = net->n_blocks[stage];
   for (int j = 0; j < nb; ++j) {
     const vv_block& B = net->blocks[stage][j];
     const bool last = (j == nb - 1);
     {   // narrow stages with many rows: the whole block as one launch (vv_block1d.hip)
-      float* dst = last ? other + (size_t)nctx * C : other;
+      float* dst = last ? (next_pad ? next_pad : other) + (size_t)nctx * C : other;
       const int fused = vv_launch_block1d(B, net->wdt, cur, dst, (int)T, C, net->eps, (hipStream_t)stream);
       if (fused < 0) return fused;
       if (fused) {
-        if (last) { *pad_out = other; cur = nullptr; }
+        if (last) { *pad_out = next_pad ? next_pad : other; cur = nullptr; }
         else { float* t = cur; cur = other; other = t; }
         continue;
       }
     }
-    float* final_dst = last ? cur + (size_t)nctx * C : nullptr;
-    if (last) *pad_out = cur;
+    float* final_dst = last ? (next_pad ? next_pad : cur) + (size_t)nctx * C : nullptr;
+    if (last) *pad_out = next_pad ? next_pad : cur;
     VV_TRY(vv_block_mixer(cur, other, (int)T, C, B.norm_w, net->eps, B.dw_w, B.dw_b, B.gamma, B.hist, stream));
     // T > 8 rows on bf16 weights: both FFN linears run on the matrix cores and the 4C-wide hidden activation is handed
     // over in bf16 (half the bytes, and the second GEMM reads its fragments straight from it: no LDS staging)
@@ -364,13 +421,30 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
   // stem input: padded [6 + T, vae] in A
   const vv_conv& stem = net->sample[0];
   if (stem.transposed || stem.stride != 1) return vv_set_error(VV_E_ARG, "vv_decoder_forward: stem must be a stride-1 conv");
-  float* pad = A;
+  // streaming: every conv reads its own padded-input region; all left contexts are placed by ONE launch up front and collected by
+  // ONE launch at the end (they were one dependent launch per conv: 8 per frame and net)
+  const bool streaming = convnet_streaming(net);
+  size_t poff[VV_MAX_STAGES + 1];
+  float* pads = nullptr;
+  vv_conv_ctx_item items[VV_MAX_STAGES + 1];
+  int n_items = 0;
+  if (streaming) {
+    pads = cvr.take(convnet_pad_floats(net, T0, poff));
+    int64_t Ti = T0;
+    for (int i = 0; i <= net->n_stages; ++i) {
+      const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
+      if (conv_ctx_of(cv) > 0) items[n_items++] = vv_conv_ctx_item{pads + poff[i], cv.state, conv_ctx_of(cv), (int)Ti, cv.cin};
+      if (cv.transposed) Ti *= cv.stride;
+    }
+    VV_TRY(vv_conv_ctx_batch(items, n_items, 0, (hipStream_t)stream));
+  }
+  float* pad = streaming ? pads + poff[0] : A;
   VV_TRY(vv_affine(latent, pre_scale, pre_bias, pad + (size_t)conv_ctx_of(stem) * stem.cin, (int64_t)T * stem.cin, stream));
   float* cur = nullptr;     // current activation buffer, `pad` holds the next conv's input
   float* other = nullptr;
   for (int i = 0; i < net->n_stages; ++i) {
     const vv_conv& cv = net->sample[i];
-    VV_TRY(conv_left_ctx(cv, pad, T, stream));
+    if (!streaming) VV_TRY(conv_left_ctx(cv, pad, T, stream));
     float* outb = (pad == A) ? Bf : A;
     vv_lin_args a;
     if (cv.transposed) {
@@ -388,22 +462,26 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
     const int C = cv.cout;
     const vv_conv& nxt = (i + 1 < net->n_stages) ? net->sample[i + 1] : net->head;
     const int nctx = conv_ctx_of(nxt);
+    float* next_pad = streaming ? pads + poff[i + 1] : nullptr;
     if (net->n_blocks[i] > 0) {
       // the last block writes straight into the next conv's padded input; which buffer that is depends on block parity:
       // block j reads cur -> writes other, then they swap.  The last block's mixer output sits in `other_last`, its
       // result may go anywhere except that buffer and hid: use the buffer holding the (dead) input of that block.
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream));
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad));
     } else {
-      hipError_t e = hipMemcpyAsync(other + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+      float* dstb = next_pad ? next_pad : other;
+      hipError_t e = hipMemcpyAsync(dstb + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
       if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_decoder_forward: %s", hipGetErrorString(e));
-      pad = other;
+      pad = dstb;
     }
   }
   const vv_conv& hd = net->head;
-  VV_TRY(conv_left_ctx(hd, pad, T, stream));
+  if (!streaming) VV_TRY(conv_left_ctx(hd, pad, T, stream));
   vv_lin_args a = lin_base(pad, (int64_t)hd.stride * hd.cin, (int)T, hd.w, hd.cout, hd.kk * hd.cin, net->wdt, wav, hd.cout);
   a.bias = hd.b;
-  return vv_linear(&a, stream);
+  VV_TRY(vv_linear(&a, stream));
+  if (streaming) VV_TRY(vv_conv_ctx_batch(items, n_items, 1, (hipStream_t)stream));
+  return 0;
 }
 
 extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64_t T0, float* feat, void* ws, vv_stream_t stream) {
@@ -418,7 +496,28 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
   float* hid = cvr.take(hel);
   int64_t T = T0;
   const vv_conv& stem = net->sample[0];
-  float* pad = A;
+  // streaming frames (T0 a multiple of the hop, every conv with a state buffer): dedicated padded-input regions, all left contexts
+  // gathered / scattered by one launch each (see vv_decoder_forward)
+  bool streaming = convnet_streaming(net);
+  {
+    int64_t Ti = T0;
+    for (int i = 0; i < net->n_stages && streaming; ++i) { if (Ti % net->sample[i].stride) streaming = false; Ti /= net->sample[i].stride; }
+  }
+  size_t poff[VV_MAX_STAGES + 1];
+  float* pads = nullptr;
+  vv_conv_ctx_item items[VV_MAX_STAGES + 1];
+  int n_items = 0;
+  if (streaming) {
+    pads = cvr.take(convnet_pad_floats(net, T0, poff));
+    int64_t Ti = T0;
+    for (int i = 0; i <= net->n_stages; ++i) {
+      const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
+      if (conv_ctx_of(cv) > 0) items[n_items++] = vv_conv_ctx_item{pads + poff[i], cv.state, conv_ctx_of(cv), (int)Ti, cv.cin};
+      Ti = (Ti + cv.stride - 1) / cv.stride;
+    }
+    VV_TRY(vv_conv_ctx_batch(items, n_items, 0, s));
+  }
+  float* pad = streaming ? pads + poff[0] : A;
   hipError_t e = hipMemcpyAsync(pad + (size_t)conv_ctx_of(stem) * stem.cin, wav, (size_t)T * stem.cin * 4, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
   float* cur = nullptr;
@@ -428,7 +527,7 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
     const vv_conv& cv = is_head ? net->head : net->sample[i];
     if (cv.transposed) return vv_set_error(VV_E_ARG, "vv_encoder_forward: transposed conv in an encoder");
     const int ctx = conv_ctx_of(cv);
-    VV_TRY(conv_left_ctx(cv, pad, T, stream));
+    if (!streaming) VV_TRY(conv_left_ctx(cv, pad, T, stream));
     // output length as the reference's non-streaming padding rule gives it (modular_vibevoice_tokenizer.py:127-133);
     // for streaming frames T is a multiple of the stride and there is no tail.
     const int64_t Tout = (T + cv.stride - 1) / cv.stride;
@@ -464,14 +563,17 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
     const int C = cv.cout;
     const vv_conv& nxt = (i + 1 < net->n_stages) ? net->sample[i + 1] : net->head;
     const int nctx = conv_ctx_of(nxt);
+    float* next_pad = streaming ? pads + poff[i + 1] : nullptr;
     if (net->n_blocks[i] > 0) {
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream));
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad));
     } else {
-      e = hipMemcpyAsync(other + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, s);
+      float* dstb = next_pad ? next_pad : other;
+      e = hipMemcpyAsync(dstb + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, s);
       if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
-      pad = other;
+      pad = dstb;
     }
   }
+  if (streaming) VV_TRY(vv_conv_ctx_batch(items, n_items, 1, s));
   return 0;
 }
 
@@ -514,7 +616,7 @@ extern "C" int vv_connector_forward(const vv_connector* c, const float* x, int R
 extern "C" size_t vv_sizeof(const char* name) {
   if (!name) return 0;
 #define S(t) if (!strcmp(name, #t)) return sizeof(t);
-  S(vv_lin_args) S(vv_kv) S(vv_llm_layer) S(vv_llm) S(vv_head_layer) S(vv_head) S(vv_dpm_coef) S(vv_block) S(vv_conv) S(vv_convnet) S(vv_connector) S(vv_prof_entry)
+  S(vv_w8) S(vv_lin_args) S(vv_kv) S(vv_llm_layer) S(vv_llm) S(vv_head_layer) S(vv_head) S(vv_dpm_coef) S(vv_block) S(vv_conv) S(vv_convnet) S(vv_connector) S(vv_prof_entry)
 #undef S
   return 0;
 }

@@ -234,9 +234,16 @@ class Engine:
                                         self.forced_dev.data_ptr(), self.sp), "vv_argmax_ids")
 
     def _seq_A(self, tok_start, tok_diff):
-        """batch-2 decode step + token selection + device-side position bookkeeping."""
-        self._seq_A1()
-        self._seq_A2(tok_start, tok_diff)
+        """batch-2 decode step + token selection + device-side position bookkeeping: the Qwen2 stack leaves its un-normalised last
+        hidden rows at the start of the workspace, vv_llm_tail does final norm + constrained logits + argmax / forced token +
+        position update in ONE launch."""
+        nv = len(self.valid_ids)
+        self._ck(self.lib.vv_llm_forward(C.byref(self.w.llm), C.byref(self.kv), self.x2.data_ptr(), self.cfg.hidden, 2,
+                                         self.lens.data_ptr(), None, None, 0, self._llm_ws.data_ptr(), self.sp), "vv_llm_forward")
+        self._ck(self.lib.vv_llm_tail(C.byref(self.w.llm), self._llm_ws.data_ptr(), self.cfg.hidden, 2, self.hidden2.data_ptr(), self.cfg.hidden,
+                                      self._w_valid.data_ptr(), nv, self._ids_dev.data_ptr(), self.logits.data_ptr(), self.token_dev.data_ptr(),
+                                      self.forced_dev.data_ptr(), self.lens.data_ptr(), tok_start, tok_diff, self.frame_ctr.data_ptr(), self.sp),
+                 "vv_llm_tail")
 
     def _seq_A1(self):
         self._ck(self.lib.vv_llm_forward(C.byref(self.w.llm), C.byref(self.kv), self.x2.data_ptr(), self.cfg.hidden, 2,

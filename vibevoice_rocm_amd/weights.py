@@ -213,6 +213,13 @@ class DeviceWeights:
         h.final_linear = L.ptr(self._mat(sd[p + "final_layer.linear.weight"]))
         h.layer = C.cast(layers, C.POINTER(L.HeadLayer))
         self._keep.append(layers)
+        # G = [P F ; F] (fp32, built once in fp64 from the matrices the kernels stream: bf16-rounded in bf16 mode): every solver-step
+        # boundary - final linear, CFG, DPM-Solver++ update, next noisy_images_proj, all linear in the modulated hidden state - is
+        # one GEMV over it (csrc/vv_fused.hip); P (F y) == (P F) y up to fp32 rounding
+        P = sd[p + "noisy_images_proj.weight"].to(device=self.device, dtype=self.wdtype).double()
+        F = sd[p + "final_layer.linear.weight"].to(device=self.device, dtype=self.wdtype).double()
+        self.head_g = self._vec(torch.cat([P @ F, F], dim=0).float())
+        h.fused_g = L.ptr(self.head_g)
         self.head = h
         self.t_mlp0 = self._mat(sd[p + "t_embedder.mlp.0.weight"])
         self.t_mlp2 = self._mat(sd[p + "t_embedder.mlp.2.weight"])
