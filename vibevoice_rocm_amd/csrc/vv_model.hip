@@ -245,7 +245,9 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   const int chained = sde_noise ? 0 : vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
   if (chained < 0) return chained;
   if (chained) return 0;
-  if (!sde_noise && vv_head_boundary_supported(h)) {
+  bool ode = !sde_noise;
+  for (int i = 0; i < n_steps && ode; ++i) ode = coef[i].cn == 0.f;          // the SDE solver (variance noise per step) keeps the three-launch boundary
+  if (ode && vv_head_boundary_supported(h)) {
     // one launch per step boundary: FinalLayer + CFG + DPM-Solver++ update + next noisy_images_proj as ONE GEMV over G = [P F ; F]
     // with the solver in its epilogue (vv_fused.hip).  The hidden rows alternate between two buffers: the boundary kernel of step i
     // reads the rows the layers of step i worked on while it writes the rows step i + 1 starts from.
