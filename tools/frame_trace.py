@@ -4,7 +4,7 @@ one frame plus per-(kernel, grid) statistics.
   run:     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ft -- python3 tools/frame_trace.py run [--model 1.5b] [--frames 40]
   reduce:  python tools/frame_trace.py reduce <kernel_trace.csv> [out_prefix]
 
-A "frame" is everything between two advance_lens kernels (diffusion tail of frame i, then the LLM step that picks token i+1)."""
+A "frame" is everything between two llm_tail (token + bookkeeping) kernels (diffusion tail of frame i, then the LLM step that picks token i+1)."""
 import csv
 import collections
 import sys
@@ -48,7 +48,7 @@ def short(name):
 def reduce(path, out_prefix=None):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    cuts = [i for i, r in enumerate(rows) if "advance_lens" in r["Kernel_Name"]]
+    cuts = [i for i, r in enumerate(rows) if "advance_lens" in r["Kernel_Name"] or "llm_tail_kernel" in r["Kernel_Name"]]
     frames = [rows[cuts[i] + 1: cuts[i + 1] + 1] for i in range(len(cuts) - 1)]
     lens = collections.Counter(len(f) for f in frames)
     n_typ = lens.most_common(1)[0][0]

@@ -1,0 +1,232 @@
+// vv_attn_decode.hip — decode attention of the per-frame LLM step (bf16 KV cache, head_dim 128): RoPE(q, new k) + KV append + GQA attention
+// for the R = 2 rows {positive, negative} (Qwen2 attention under modeling_vibevoice.py:187-199; reference call sites
+// modeling_vibevoice_inference.py:478-480,581-583).
+//
+// Latency-bound (tools/attn_lab.cpp): the previous kernel spent 2.9 us until q / RoPE were in registers (56 scalar loads per lane),
+// 5 us in a per-key online softmax with two expf per key on 16 waves sharing one CU, and 4.7 us merging lane groups with ds_bpermute
+// chains plus a 16-step serial loop per output.  Here:
+//   * q, new k, new v and the RoPE table come in with 14 16-byte loads per lane, issued before lens is even known;
+//   * 16 lanes share a key (one DPP row: the dot product is 4 DPP adds), 4 keys per lane group are scored per batch and folded into the
+//     running maximum ONCE per batch, in the log2 domain (v_exp_f32; the scale carries log2 e);
+//   * all lane groups of the block merge through LDS in one step (every output thread folds the 16-32 partial maxima itself:
+//     one barrier, no cross-lane chains);
+//   * 512 threads per (row, q head): a CU pulls its 2 x S x 256 B of K/V at ~95 GB/s, which is the floor of this layout at
+//     S ~ 500 (2.4 us); long contexts (cfg 4: S up to 4 500) split the keys over gridDim.z blocks whose partial (m, l, acc) meet
+//     in the last-arriving block (agent-scope release / acquire around a ticket, cdna_hip_programming.md Guideline 16).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "vv_hip.h"
+#include "vv_common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef unsigned int att_raw __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void unpack8(const att_raw v, float (&o)[8]) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u); o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u); o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ float gsum16(float v) {       // sum over the 16 lanes of a DPP row, result in every lane of the row
+#define VV_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+  VV_DPP_ADD(0xB1); VV_DPP_ADD(0x4E); VV_DPP_ADD(0x141); VV_DPP_ADD(0x140);
+#undef VV_DPP_ADD
+  return v;
+}
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ unsigned bf16_bits(float f) {   // round to nearest even (finite inputs: projections of finite activations)
+  const unsigned u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+#define ATT_UNR 4
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer, const float2* rope, const int* lens,
+                                                             float* out, int64_t ldo, float* part, int* tickets) {
+  constexpr int d = 128, half = 64, NG = NW * 4, EPL = 8;
+  __shared__ __attribute__((aligned(16))) float sacc[NG][d];
+  __shared__ float sm_[NG], sl_[NG];
+  __shared__ int s_last;
+  const int r = blockIdx.y, h = blockIdx.x, split = blockIdx.z, nsplit = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane & 15, gi = lane >> 4, grp = wave * 4 + gi;
+  const int e0 = gl * EPL;
+  const bool lo = e0 < half;
+  const int pe0 = lo ? e0 + half : e0 - half;               // half rotation pairs (i, i + d/2)
+  const float* row = qkv + (int64_t)r * ld;
+  const int gsz = heads / kv.kv_heads, kvh = h / gsz;
+  const float* qp = row + h * d;
+  const float* kp = row + (heads + kvh) * d;
+  const float* vp = row + (heads + kv.kv_heads + kvh) * d;
+  const float4 qa0 = *reinterpret_cast<const float4*>(qp + e0), qa1 = *reinterpret_cast<const float4*>(qp + e0 + 4);
+  const float4 qb0 = *reinterpret_cast<const float4*>(qp + pe0), qb1 = *reinterpret_cast<const float4*>(qp + pe0 + 4);
+  const float4 ka0 = *reinterpret_cast<const float4*>(kp + e0), ka1 = *reinterpret_cast<const float4*>(kp + e0 + 4);
+  const float4 kb0 = *reinterpret_cast<const float4*>(kp + pe0), kb1 = *reinterpret_cast<const float4*>(kp + pe0 + 4);
+  const float4 vn0 = *reinterpret_cast<const float4*>(vp + e0), vn1 = *reinterpret_cast<const float4*>(vp + e0 + 4);
+  const float2* rp = rope + (int64_t)r * half + (lo ? e0 : pe0);
+  const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 2);
+  const float4 r2 = *reinterpret_cast<const float4*>(rp + 4), r3 = *reinterpret_cast<const float4*>(rp + 6);
+  const int pos = lens[r];
+  const int64_t base = ((((int64_t)layer * kv.rows + r) * kv.kv_heads + kvh) * kv.s_max) * d;
+  bf16_t* kc = reinterpret_cast<bf16_t*>(kv.k) + base;
+  bf16_t* vc = reinterpret_cast<bf16_t*>(kv.v) + base;
+  const int per = (pos + nsplit - 1) / nsplit;              // this block's keys [ks, ke) of the pos cached ones
+  const int ks = split * per, ke = min(pos, ks + per);
+  att_raw kraw[2][ATT_UNR], vraw[2][ATT_UNR];
+  auto issue_kv = [&](int buf, int s0) {
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      const int sidx = s0 + u * NG;
+      const int sc = sidx < ke ? sidx : 0;
+      kraw[buf][u] = *reinterpret_cast<const att_raw*>(kc + (int64_t)sc * d + e0);
+      vraw[buf][u] = *reinterpret_cast<const att_raw*>(vc + (int64_t)sc * d + e0);
+    }
+  };
+  const int s_first = ks + grp;
+  if (s_first < ke) issue_kv(0, s_first);
+  const float qsc = rsqrtf((float)d) * 1.4426950408889634f;  // scores in the log2 domain
+  const float cs[8] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z}, sn[8] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
+  const float qa[8] = {qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w}, qb[8] = {qb0.x, qb0.y, qb0.z, qb0.w, qb1.x, qb1.y, qb1.z, qb1.w};
+  const float ka[8] = {ka0.x, ka0.y, ka0.z, ka0.w, ka1.x, ka1.y, ka1.z, ka1.w}, kb[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
+  const float vn[8] = {vn0.x, vn0.y, vn0.z, vn0.w, vn1.x, vn1.y, vn1.z, vn1.w};
+  float q[EPL], kn[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) {      // q * cos + rotate_half(q) * sin: first half takes -x2, second half +x1
+    q[j] = (lo ? qa[j] * cs[j] - qb[j] * sn[j] : qa[j] * cs[j] + qb[j] * sn[j]) * qsc;
+    kn[j] = lo ? ka[j] * cs[j] - kb[j] * sn[j] : ka[j] * cs[j] + kb[j] * sn[j];
+  }
+  float mmax = -INFINITY, lsum = 0.f, acc[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+  auto consume = [&](int buf, int s0) {
+    float dot[ATT_UNR], vx[ATT_UNR][EPL];
+    float bm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      float kx[EPL];
+      unpack8(kraw[buf][u], kx);
+      unpack8(vraw[buf][u], vx[u]);
+      float dd = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) dd = fmaf(q[j], kx[j], dd);
+      dd = gsum16(dd);
+      dot[u] = (s0 + u * NG < ke) ? dd : -INFINITY;
+      bm = fmaxf(bm, dot[u]);
+    }
+    if (bm == -INFINITY) return;                 // uniform over the lane group: no key in this batch
+    const float mn = fmaxf(mmax, bm);
+    const float corr = ex2(mmax - mn);           // exp2(-inf) = 0 on the first batch
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] *= corr;
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      const float p = ex2(dot[u] - mn);          // masked keys: exp2(-inf) = 0
+      ps += p;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vx[u][j], acc[j]);
+    }
+    lsum = lsum * corr + ps;
+    mmax = mn;
+  };
+  const int stride = NG * ATT_UNR;
+  for (int s0 = s_first; s0 < ke; s0 += 2 * stride) {       // two batches in flight, buffers with fixed roles
+    if (s0 + stride < ke) issue_kv(1, s0 + stride);
+    consume(0, s0);
+    if (s0 + stride >= ke) break;
+    if (s0 + 2 * stride < ke) issue_kv(0, s0 + 2 * stride);
+    consume(1, s0 + stride);
+  }
+  if (split == 0 && grp == 0) {
+    // the new token itself, straight from the projection (its cache slot may not be written yet by the block that owns it)
+    float dd = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) dd = fmaf(q[j], kn[j], dd);
+    dd = gsum16(dd);
+    const float mn = fmaxf(mmax, dd), corr = ex2(mmax - mn), p = ex2(dd - mn);
+    lsum = lsum * corr + p;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = fmaf(p, vn[j], acc[j] * corr);
+    mmax = mn;
+    if (h % gsz == 0) {                          // one writer per (row, kv head): append k, v at slot pos
+      att_raw pk, pv;
+      pk.x = bf16_bits(kn[0]) | (bf16_bits(kn[1]) << 16); pk.y = bf16_bits(kn[2]) | (bf16_bits(kn[3]) << 16);
+      pk.z = bf16_bits(kn[4]) | (bf16_bits(kn[5]) << 16); pk.w = bf16_bits(kn[6]) | (bf16_bits(kn[7]) << 16);
+      pv.x = bf16_bits(vn[0]) | (bf16_bits(vn[1]) << 16); pv.y = bf16_bits(vn[2]) | (bf16_bits(vn[3]) << 16);
+      pv.z = bf16_bits(vn[4]) | (bf16_bits(vn[5]) << 16); pv.w = bf16_bits(vn[6]) | (bf16_bits(vn[7]) << 16);
+      *reinterpret_cast<att_raw*>(kc + (int64_t)pos * d + e0) = pk;
+      *reinterpret_cast<att_raw*>(vc + (int64_t)pos * d + e0) = pv;
+    }
+  }
+  // every lane group's (m, l, acc[128]) to LDS, then each output thread folds them itself: one barrier
+  if (gl == 0) { sm_[grp] = mmax; sl_[grp] = lsum; }
+  *reinterpret_cast<float4*>(&sacc[grp][e0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(&sacc[grp][e0 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  __syncthreads();
+  float M = -INFINITY, num = 0.f, den = 0.f;
+  if (tid < d) {
+#pragma unroll
+    for (int gg = 0; gg < NG; ++gg) M = fmaxf(M, sm_[gg]);
+#pragma unroll 8
+    for (int gg = 0; gg < NG; ++gg) {
+      const float w = ex2(sm_[gg] - M);          // a group without keys has m = -inf: weight 0 (M is finite: split 0 holds the new token, every other split at least one key or it is skipped below)
+      den = fmaf(w, sl_[gg], den);
+      num = fmaf(w, sacc[gg][tid], num);
+    }
+  }
+  if (nsplit == 1) {
+    if (tid < d) out[(int64_t)r * ldo + h * d + tid] = num / den;
+    return;
+  }
+  // split keys: partial (M, den, num[128]) per block; the block that draws the last ticket folds them
+  float* pp = part + (((int64_t)r * heads + h) * nsplit + split) * (d + 2);
+  if (tid < d) {
+    const bool empty = (ke <= ks) && split != 0;
+    pp[2 + tid] = empty ? 0.f : num;
+    if (tid == 0) { pp[0] = empty ? -INFINITY : M; pp[1] = empty ? 0.f : den; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int tk = __hip_atomic_fetch_add(&tickets[r * heads + h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (tk == nsplit - 1);
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&tickets[r * heads + h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+  }
+  __syncthreads();
+  if (s_last && tid < d) {
+    const float* p0 = part + (((int64_t)r * heads + h) * nsplit) * (d + 2);
+    float MM = -INFINITY;
+    for (int sgi = 0; sgi < nsplit; ++sgi) MM = fmaxf(MM, p0[sgi * (d + 2)]);
+    float nn = 0.f, dn = 0.f;
+    for (int sgi = 0; sgi < nsplit; ++sgi) {
+      const float* ps = p0 + sgi * (d + 2);
+      const float w = ex2(ps[0] - MM);
+      dn = fmaf(w, ps[1], dn);
+      nn = fmaf(w, ps[2 + tid], nn);
+    }
+    out[(int64_t)r * ldo + h * d + tid] = nn / dn;
+  }
+}
+
+}  // namespace
+
+// 1 launched, 0 not covered (caller falls back to the generic kernel), < 0 error.  part / tickets: split-key workspace or null (nsplit = 1)
+int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float2* rope, const int* lens, float* out,
+                          int64_t ldo, float* part, int* tickets, int nsplit, hipStream_t s) {
+  if (kv->kvdt != VV_BF16 || kv->head_dim != 128) return 0;
+  if (((uintptr_t)qkv % 16) || (ld_qkv % 4) || ((uintptr_t)rope % 16) || ((uintptr_t)kv->k % 16) || ((uintptr_t)kv->v % 16)) return 0;
+  if (!part || !tickets || nsplit < 1) nsplit = 1;
+  if (nsplit > 16) nsplit = 16;
+  hipLaunchKernelGGL((attn_decode_kernel<8>), dim3(heads, R, nsplit), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_attn_decode: %s", hipGetErrorString(e));
+  return 1;
+}

@@ -44,6 +44,11 @@ static inline void vv_chain_set_dbg_mode(int) {}
 static inline void vv_chain_set_dbg(int, int) {}
 static inline void vv_chain_set_head(int) {}
 #endif
+// vv_attn_decode.hip: bf16 KV cache, head_dim 128; part / tickets = split-key workspace ([R, heads, nsplit, 130] floats, [R, heads] zeroed ints) or null
+int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float2* rope, const int* lens, float* out,
+                          int64_t ldo, float* part, int* tickets, int nsplit, hipStream_t s);
+int vv_attn_decode_ws(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table, const int* lens, float* out,
+                      int64_t ldo, float* part, int* tickets, int nsplit, vv_stream_t stream);
 // vv_fused.hip
 int vv_head_init_fused(const vv_head* h, const float* noise, float* Xs, float* Ms, float* h0, int64_t ldh, hipStream_t s);
 bool vv_head_boundary_supported(const vv_head* h);

@@ -43,13 +43,17 @@ static inline void use_w8(vv_lin_args& a, const vv_w8& q, const vv_w8* q2 = null
 // from this many rows on, a bf16-weight LLM forward is a prompt prefill: activations are cast to bf16 once per GEMM and both
 // operands stream from global on the matrix cores with 128-row tiles (every weight fragment reused by 4 row tiles)
 #define VV_PREFILL_ROWS 64
+// decode attention over long contexts splits the keys over up to this many blocks per (row, q head) (vv_attn_decode.hip)
+#define VV_ATT_ROWS 8
+#define VV_ATT_MAX_SPLIT 16
 
 extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   if (!m || R <= 0) return 0;
   const size_t qkv = (size_t)(m->heads + 2 * m->kv_heads) * m->head_dim;
   const size_t widest = (size_t)(m->inter > m->hidden ? m->inter : m->hidden);
   return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter) +
-         al((size_t)R * m->head_dim) + (R >= VV_PREFILL_ROWS ? al((size_t)R * widest / 2 + 64) : 0);
+         al((size_t)R * m->head_dim) + (R >= VV_PREFILL_ROWS ? al((size_t)R * widest / 2 + 64) : 0) +
+         al((size_t)VV_ATT_ROWS * m->heads * VV_ATT_MAX_SPLIT * (m->head_dim + 2)) + al((size_t)VV_ATT_ROWS * m->heads);   // split-key decode attention
 }
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
@@ -72,6 +76,17 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   VV_TRY(vv_rope_table(lens, m->inv_freq, R, d, rope, stream));
   const bool prefill = (R >= VV_PREFILL_ROWS) && m->wdt == VV_BF16 && H % 16 == 0 && m->inter % 16 == 0 && qd % 16 == 0;
   void* xb = prefill ? (void*)c.take((size_t)R * (m->inter > H ? m->inter : H) / 2 + 64) : nullptr;
+  float* att_part = c.take((size_t)VV_ATT_ROWS * m->heads * VV_ATT_MAX_SPLIT * (d + 2));
+  int* att_tickets = reinterpret_cast<int*>(c.take((size_t)VV_ATT_ROWS * m->heads));
+  // contexts beyond ~1K keys: one block per (row, q head) would pull all of its K / V through a single CU (~95 GB/s: 8 us at S = 3000)
+  const bool decode = (cache_rows == nullptr && R <= kv->rows);
+  int att_split = 1;
+  if (decode && R <= VV_ATT_ROWS && kv->s_max > 1024) {
+    att_split = (kv->s_max + 511) / 512;
+    if (att_split > VV_ATT_MAX_SPLIT) att_split = VV_ATT_MAX_SPLIT;
+    hipError_t e = hipMemsetAsync(att_tickets, 0, (size_t)VV_ATT_ROWS * m->heads * sizeof(int), s);
+    if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_llm_forward: %s", hipGetErrorString(e));
+  }
   void* xb2 = prefill ? (void*)act : nullptr;      // bf16 SwiGLU output [R, inter] lives in the (otherwise unused) fp32 act buffer
   for (int l = 0; l < m->layers; ++l) {
     const vv_llm_layer& L = m->layer[l];
@@ -86,8 +101,8 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       use_w8(a, L.q_qkv);
     }
     VV_TRY(vv_linear(&a, stream));
-    if (cache_rows == nullptr && R <= kv->rows) {
-      VV_TRY(vv_attn_decode(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, stream));   // decode: RoPE + append fused
+    if (decode) {
+      VV_TRY(vv_attn_decode_ws(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, att_part, att_tickets, att_split, stream));   // decode: RoPE + append fused
     } else {
       VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, rope, lens, cache_rows, stream));
       VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
