@@ -34,32 +34,51 @@ import torch
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
-def build_workload(cfg, frames, voice_frames, seed=1):
-    """Synthetic processor output: ids uniform in [0,1000), one voice prompt, forced schedule."""
+WORKLOADS = {
+    # BASELINE.json configs[1..4] restated synthetically: model preset, speakers, voice frames per speaker, text
+    # tokens, frames, frames per turn (speech_end, speech_start between turns), solver steps, weight quantisation, prefill chunk
+    "cfg2": dict(model="1.5b", speakers=1, voice_frames=203, text=88, frames=225, turn=0, steps=20, quant=None, chunk=1024),
+    "cfg3": dict(model="1.5b", speakers=4, voice_frames=203, text=168, frames=450, turn=75, steps=20, quant=None, chunk=1024),
+    "cfg4": dict(model="7b", speakers=2, voice_frames=203, text=1042, frames=2250, turn=75, steps=20, quant=None, chunk=1024),
+    "cfg5": dict(model="7b", speakers=2, voice_frames=203, text=1042, frames=2250, turn=75, steps=50, quant="fp8", chunk=512),
+}
+
+
+def build_workload(cfg, frames, voice_frames, seed=1, speakers=1, text=88, turn=0):
+    """Synthetic processor output: ids uniform in [0,1000), `speakers` voice prompts laid out as the processor does
+    (" Speaker i:" prefix, speech_start, placeholders, speech_end, newline), forced schedule of `frames` speech_diffusion tokens with
+    `speech_end, speech_start` every `turn` frames (0: one turn), then speech_end, eos."""
     V = cfg.vocab
     ST, SE, SD, EOS = V - 4, V - 3, V - 2, V - 1
     g = torch.Generator().manual_seed(seed)
     lim = min(1000, V - 8)
-    sys_t = torch.randint(0, lim, (30,), generator=g)
-    pre = torch.randint(0, lim, (6,), generator=g)
-    txt = torch.randint(0, lim, (88,), generator=g)
-    ids = torch.cat([sys_t, pre, torch.tensor([ST]), torch.full((voice_frames,), SD), torch.tensor([SE]), txt, torch.tensor([ST])])
-    mask = torch.zeros(ids.shape[0], dtype=torch.bool)
-    mask[37: 37 + voice_frames] = True
+    parts, masks = [torch.randint(0, lim, (30,), generator=g)], [torch.zeros(30, dtype=torch.bool)]
+    for _ in range(speakers):
+        pre = torch.randint(0, lim, (6,), generator=g)
+        parts += [pre, torch.tensor([ST]), torch.full((voice_frames,), SD), torch.tensor([SE])]
+        masks += [torch.zeros(7, dtype=torch.bool), torch.ones(voice_frames, dtype=torch.bool), torch.zeros(1, dtype=torch.bool)]
+    parts += [torch.randint(0, lim, (text,), generator=g), torch.tensor([ST])]
+    masks += [torch.zeros(text + 1, dtype=torch.bool)]
+    ids, mask = torch.cat(parts), torch.cat(masks)
     gv = torch.Generator().manual_seed(seed + 1)
-    voice = torch.randn(voice_frames * cfg.hop - 1234, generator=gv)
-    voice = voice * (10 ** (-25 / 20) / (voice.pow(2).mean().sqrt() + 1e-6))          # -25 dBFS like AudioNormalizer
-    forced = [SD] * frames + [SE, EOS]
+    voice = torch.randn(speakers, voice_frames * cfg.hop - 1234, generator=gv)
+    voice = voice * (10 ** (-25 / 20) / (voice.pow(2).mean(-1, keepdim=True).sqrt() + 1e-6))          # -25 dBFS like AudioNormalizer
+    forced = []
+    for f in range(frames):
+        if turn and f and f % turn == 0:
+            forced += [SE, ST]
+        forced.append(SD)
+    forced += [SE, EOS]
     gn = torch.Generator().manual_seed(seed + 2)
     noise = torch.randn(frames, cfg.latent, generator=gn)
     gs = torch.Generator().manual_seed(seed + 3)
-    speech_noise = (torch.randn(1, generator=gs), torch.randn(1, voice_frames, cfg.ac_dim, generator=gs))
+    speech_noise = (torch.randn(speakers, generator=gs), torch.randn(speakers, voice_frames, cfg.ac_dim, generator=gs))
 
     class Tok:
         speech_start_id, speech_end_id, speech_diffusion_id, eos_token_id, bos_token_id, pad_id = ST, SE, SD, EOS, None, 0
 
-    return dict(input_ids=ids[None], speech_input_mask=mask[None], speech_tensors=voice[None],
-                speech_masks=torch.ones(1, voice_frames, dtype=torch.bool), forced=forced, noise=noise,
+    return dict(input_ids=ids[None], speech_input_mask=mask[None], speech_tensors=voice,
+                speech_masks=torch.ones(speakers, voice_frames, dtype=torch.bool), forced=forced, noise=noise,
                 speech_noise=speech_noise, tok=Tok(), special=dict(speech_start=ST, speech_end=SE, speech_diffusion=SD, eos=EOS))
 
 
@@ -87,8 +106,11 @@ def bytes_per_frame(cfg, n_steps, mean_ctx, wbytes=2):
 
 def run_generate(model, wl, cfg_scale, n_frames=None, use_voice=True):
     forced = wl["forced"] if n_frames is None else [wl["special"]["speech_diffusion"]] * n_frames + wl["forced"][-2:]
+    # generate() caps a dialogue at 2x the prompt length (max_length_times, reference :420): the synthetic prompts are shorter than
+    # a real script of that duration, so the cap is lifted to fit the forced schedule
+    mlt = max(2, -(-len(forced) // wl["input_ids"].shape[1]) + 1)
     kw = dict(input_ids=wl["input_ids"], tokenizer=wl["tok"], cfg_scale=cfg_scale, forced_tokens=forced, noise=wl["noise"],
-              generation_config={"do_sample": False}, show_progress_bar=False)
+              generation_config={"do_sample": False}, show_progress_bar=False, max_length_times=mlt)
     if use_voice:
         kw.update(speech_tensors=wl["speech_tensors"], speech_masks=wl["speech_masks"], speech_input_mask=wl["speech_input_mask"],
                   speech_noise=wl["speech_noise"])
@@ -124,7 +146,90 @@ def roofline_leg(model, wl, cfg_scale, frames=12):
     return ents
 
 
-def first_chunk_leg(model, wl, cfg_scale, runs=5):
+def kernel_source_sha():
+    """Content hash of the kernel sources + C ABI header: ties a PMC traffic file to the code it was measured on (the GPU box has no
+    .git, and the driver's bench box neither)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vibevoice_rocm_amd", "csrc")
+    for fn in sorted(os.listdir(d)) + ["../../include/vv_hip.h"]:
+        path = os.path.join(d, fn)
+        if os.path.isfile(path) and fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(shape_key):
+    """HBM-side bytes per launch of a shape from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE inside graph replays of real
+    frames, x2 gfx950 correction; tools/pmc_frames.py) - only when that file was measured on THIS kernel source, else None."""
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(tp) as f:
+            j = json.load(f)
+        if j.get("kernel_src_sha") != kernel_source_sha():
+            return None, f"profiles/pmc_traffic.json was measured on kernel source {j.get('kernel_src_sha')}, this tree is {kernel_source_sha()}"
+        return j.get("per_launch_bytes", {}).get(shape_key), j.get("note")
+    except Exception as e:      # noqa: BLE001
+        return None, repr(e)
+
+
+def llm_prefill_flops(cfg, L0):
+    """2 x M x N x K over the Qwen2 linears of an L0-row prefill + causal attention (QK^T and PV, half the square)."""
+    H, I, qd, kvd = cfg.hidden, cfg.inter, cfg.q_dim, cfg.kv_dim
+    lin = 2.0 * L0 * (H * (qd + 2 * kvd) + qd * H + 3 * H * I)
+    att = 2.0 * 2.0 * cfg.heads * cfg.head_dim * L0 * (L0 + 1) / 2
+    return cfg.layers * (lin + att)
+
+
+def encoder_flops(cfg, T):
+    """Dense conv + Block1D FFN flops of a whole-utterance acoustic encode of T samples (depthwise taps and norms ignored)."""
+    rr = list(reversed(cfg.ac_ratios))
+    fl, t, c_in = 0.0, T, 1
+    for i, depth in enumerate(cfg.ac_depths):
+        c = cfg.ac_filters * 2 ** i
+        k, s = (7, 1) if i == 0 else (2 * rr[i - 1], rr[i - 1])
+        t = -(-t // s)
+        fl += 2.0 * t * c * k * c_in
+        fl += depth * 2.0 * t * (2 * 4 * c * c)
+        c_in = c
+    return fl + 2.0 * t * cfg.ac_dim * 7 * c_in
+
+
+def first_chunk_parts(model, wl, cfg, runs=5):
+    """The two matrix-core legs of the first-chunk latency timed with HIP events on the engine stream, against the dense bf16 MFMA
+    peak (2.5 PFLOP/s, MI355X_MICROARCH.md): voice-prompt encode (acoustic encoder over the whole prompt + connector) and LLM prefill."""
+    eng = model.engine
+    dev = eng.device
+    vt = wl["speech_tensors"].to(dev).float()
+    L0 = wl["input_ids"].shape[1]
+    x0 = torch.randn(L0, cfg.hidden, device=dev) * 0.02
+    V = cfg.vocab
+    eng.begin_sequence(L0 + 64, [V - 4, V - 3, V - 2, V - 1])
+
+    def timed(fn):
+        ts = []
+        for _ in range(runs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(eng.stream):
+                e0.record(eng.stream)
+                fn()
+                e1.record(eng.stream)
+            eng.stream.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+    ms_v = timed(lambda: model._process_speech_inputs(vt, wl["speech_masks"], *wl["speech_noise"]))
+    ms_p = timed(lambda: eng.prefill(x0, row=0, pos0=0))
+    fv = sum(encoder_flops(cfg, int(vt.shape[1])) for _ in range(vt.shape[0]))
+    fp = llm_prefill_flops(cfg, L0)
+    peak = 2500.0
+    return {"voice_encode": {"ms": round(ms_v, 3), "gflop": round(fv / 1e9, 1), "tflops": round(fv / ms_v / 1e9, 1), "frac_of_mfma_peak": round(fv / ms_v / 1e9 / peak, 4)},
+            "llm_prefill": {"ms": round(ms_p, 3), "rows": L0, "gflop": round(fp / 1e9, 1), "tflops": round(fp / ms_p / 1e9, 1), "frac_of_mfma_peak": round(fp / ms_p / 1e9 / peak, 4)},
+            "mfma_peak_tflops": peak, "note": "HIP events on the engine stream, median of %d; dense bf16 MFMA peak 2.5 PFLOP/s" % runs}
+
+
+def first_chunk_leg(model, wl, cfg_scale, runs=5, gen_kw=None):
     """p50 latency from generate() entry to the first 3200-sample chunk on the host (voice encode + prefill + 1 frame),
     through the AudioStreamer path the reference's streaming callers use."""
     from vibevoice_rocm_amd.streamer import AudioStreamer
@@ -147,7 +252,7 @@ def first_chunk_leg(model, wl, cfg_scale, runs=5):
         t0 = time.perf_counter()
         model.generate(input_ids=wl["input_ids"], tokenizer=wl["tok"], cfg_scale=cfg_scale, forced_tokens=forced, noise=wl["noise"],
                        speech_tensors=wl["speech_tensors"], speech_masks=wl["speech_masks"], speech_input_mask=wl["speech_input_mask"],
-                       speech_noise=wl["speech_noise"], audio_streamer=st, generation_config={"do_sample": False})
+                       speech_noise=wl["speech_noise"], audio_streamer=st, generation_config={"do_sample": False}, **(gen_kw or {}))
         lat.append(1e3 * (st.t_first - t0))
     lat.sort()
     return dict(p50_ms=round(lat[len(lat) // 2], 2), min_ms=round(lat[0], 2), max_ms=round(lat[-1], 2), runs=runs,
@@ -205,34 +310,68 @@ def fp8_leg(cfg, sd, device, args, wl):
                      "(weight_quant='fp8'), not the headline metric")
 
 
-def cpu_baseline_leg(model, cfg, cfg_scale, n_steps, frames=12, prompt=64):
-    """The CPU oracle on a bounded sample of the same workload (kind: port)."""
+def cpu_baseline_leg(sd_dev, cfg, frames=4, timed_runs=3):
+    """BASELINE.md section 3 / SURVEY.md section 8d cfg 1 restated on the CPU oracle (kind "port"): VibeVoice-1.5B shapes, fp32, CFG = 1.0,
+    10 solver steps, 1 speaker with a 70-frame voice prompt through process_speech_inputs, a ~170-token prompt, forced speech_diffusion
+    frames.  One warm-up + `timed_runs` timed passes of the frame loop (median), per-component seconds per frame; the once-per-utterance
+    legs (voice encode, prefill) are timed once.  Bounded to a few frames so that the default bench run stays within minutes: the
+    per-frame cost does not depend on how many frames follow (KV growth over 4 frames is negligible)."""
     from oracle import vv_oracle as O
-    # a 1-GPU box's CPU share is 16 cores even when the affinity mask lists the whole host: more threads only thrash
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = min(len(os.sched_getaffinity(0)), 16)       # a 1-GPU box's CPU share is 16 cores even when the mask lists the whole host
     torch.set_num_threads(cores)
-    log(f"cpu baseline: {cores} threads, copying weights to host")
-    sd = {}
-    # the oracle computes in fp32 on the bf16-rounded weights the GPU path streams
-    from vibevoice_rocm_amd.synth import synth_state_dict_torch
-    src = model._bench_sd
-    for k, v in src.items():
-        sd[k] = v.detach().float().cpu()
+    log(f"cpu baseline: {cores} threads, copying weights to host (fp32)")
+    sd = {k: v.detach().float().cpu() for k, v in sd_dev.items()}
     V = cfg.vocab
     special = dict(speech_start=V - 4, speech_end=V - 3, speech_diffusion=V - 2, eos=V - 1)
-    g = torch.Generator().manual_seed(11)
-    ids = torch.randint(0, min(1000, V - 8), (prompt,), generator=g).tolist() + [special["speech_start"]]
-    noise = torch.randn(frames, cfg.latent, generator=g)
-    forced = [special["speech_diffusion"]] * frames + [special["speech_end"], special["eos"]]
+    wl = build_workload(cfg, frames, 70, seed=7, speakers=1, text=57)           # 30 + 6 + 1 + 70 + 1 + 57 + 1 = 166 prompt tokens
     ocfg = cfg.as_dict()
-    log("cpu baseline: weights on host, running the oracle")
+    ids = wl["input_ids"][0].tolist()
     t0 = time.time()
-    res = O.generate(sd, ocfg, ids, None, None, special, noise, cfg_scale=cfg_scale, n_steps=n_steps, forced_tokens=forced)
-    dt = time.time() - t0
-    audio_s = len(res.audio) * cfg.hop / 24000.0
-    return dict(value=audio_s / dt, unit="audio-sec/s", cores=cores, kind="port",
-                sample=f"oracle/vv_oracle.py generate(): {prompt + 1}-token prompt (no voice prompt), {frames} frames, CFG={cfg_scale}, "
-                       f"{n_steps} steps, fp32 torch-CPU on the bf16-rounded weights, {dt:.1f} s wall")
+    _, conn = O.process_speech_inputs(sd, ocfg, wl["speech_tensors"], wl["speech_masks"], *wl["speech_noise"])
+    t_voice = time.time() - t0
+    # per-component timers around the oracle's own functions
+    acc = {}
+    names = dict(llm_forward="llm", sample_speech_tokens="head", tokenizer_decoder="decode", semantic_encode="semantic", connector="connectors")
+    orig = {n: getattr(O, n) for n in names}
+
+    def wrap(n):
+        f = orig[n]
+
+        def g(*a, **k):
+            t = time.perf_counter()
+            r = f(*a, **k)
+            acc[names[n]] = acc.get(names[n], 0.0) + time.perf_counter() - t
+            return r
+        return g
+    for n in names:
+        setattr(O, n, wrap(n))
+    runs = []
+    try:
+        for i in range(1 + timed_runs):
+            acc.clear()
+            t0 = time.time()
+            res = O.generate(sd, ocfg, ids, wl["speech_input_mask"][0], conn, special, wl["noise"], cfg_scale=1.0, n_steps=10, forced_tokens=wl["forced"])
+            dt = time.time() - t0
+            runs.append((dt, dict(acc)))
+            log(f"cpu baseline pass {i}: {dt:.1f} s")
+    finally:
+        for n in names:
+            setattr(O, n, orig[n])
+    timed = sorted(runs[1:], key=lambda r: r[0])
+    dt, comp = timed[len(timed) // 2]
+    n_fr = len(res.audio)
+    # the first llm_forward call of a pass is the prompt prefill: measured apart from the per-frame steps
+    k0 = O.KVCache(cfg.layers)
+    t0 = time.perf_counter()
+    O.llm_forward(sd, ocfg, sd["model.language_model.embed_tokens.weight"][torch.tensor(ids)], k0, 0)
+    t_prefill = time.perf_counter() - t0
+    per_frame = {k: round((v - (t_prefill if k == "llm" else 0.0)) / n_fr, 4) for k, v in comp.items()}
+    frame_s = (dt - t_prefill) / n_fr
+    return dict(value=round((cfg.hop / 24000.0) / frame_s, 4), unit="audio-sec/s", cores=cores, kind="port",
+                seconds_per_frame=round(frame_s, 4), per_frame_seconds=per_frame, prefill_seconds=round(t_prefill, 2), voice_encode_seconds=round(t_voice, 2),
+                sample=f"BASELINE.md section 3 (cfg 1 restated): oracle/vv_oracle.py on 1.5B shapes, fp32, CFG=1.0, 10 DPM-Solver++ steps, {len(ids)}-token prompt with a "
+                       f"70-frame voice prompt, {n_fr} forced frames per pass, 1 warm-up + {timed_runs} timed passes (median {dt:.1f} s incl. {t_prefill:.1f} s prefill); "
+                       "value = steady-state frames only (per-frame LLM pos+neg, head, decode, semantic, connectors)")
 
 
 _T0 = time.time()
@@ -247,18 +386,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="1.5b")
-    ap.add_argument("--frames", type=int, default=225)
-    ap.add_argument("--voice-frames", type=int, default=203)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS),
+                    help="BASELINE.json configs[1..4]; cfg2 (1.5B, 1 speaker, 30 s) is the headline the metric is quoted on")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--voice-frames", type=int, default=None)
     ap.add_argument("--cfg-scale", type=float, default=2.0)
-    ap.add_argument("--ddpm-steps", type=int, default=20)
+    ap.add_argument("--ddpm-steps", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-fp8-leg", dest="fp8_leg", action="store_false", help="skip the extra weight-only-fp8 leg")
     ap.add_argument("--concurrent", type=int, default=3, help="extra leg: N independent dialogues concurrently on one GPU (0/1 = skip)")
+    ap.add_argument("--first-chunk-runs", type=int, default=5)
     args = ap.parse_args()
+    W = WORKLOADS[args.workload]
+    args.model = args.model or W["model"]
+    args.frames = args.frames or W["frames"]
+    args.voice_frames = args.voice_frames or W["voice_frames"]
+    args.ddpm_steps = args.ddpm_steps or W["steps"]
+    headline = args.workload == "cfg2"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -291,16 +439,26 @@ def main():
     if world > 1:
         sd = vd.broadcast_state_dict(sd, cfg, dtype, device, src=0)
     log("weights ready")
-    model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
+    model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs,
+                                                       weight_quant=W["quant"] if dtype == torch.bfloat16 else None)
     log(f"engine ready ({model.engine.w.nbytes() / 1e9:.2f} GB resident)")
-    model._bench_sd = sd if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    model._bench_sd_all = sd if (rank == 0 and world == 1 and (args.concurrent > 1 or args.fp8_leg)) else None
-    if model._bench_sd is None and model._bench_sd_all is None:
+    single = world == 1            # the diagnostic legs run at N = 1 only (other ranks would just wait at the final barrier)
+    keep_sd = rank == 0 and single and headline and (not args.no_cpu_baseline or args.concurrent > 1 or args.fp8_leg)
+    if not keep_sd:
         del sd
+        sd = None
     model.set_ddpm_inference_steps(args.ddpm_steps)
-    wl = build_workload(cfg, args.frames, args.voice_frames, seed=1 + rank)     # every rank its own dialogue
-    for k in ("input_ids", "speech_input_mask", "speech_tensors", "speech_masks"):
-        wl[k] = wl[k].to(device) if k == "speech_tensors" else wl[k]
+    wl = build_workload(cfg, args.frames, args.voice_frames, seed=1 + rank, speakers=W["speakers"], text=W["text"], turn=W["turn"])     # every rank its own dialogue
+    wl["speech_tensors"] = wl["speech_tensors"].to(device)
+    gen_kw = dict(prefill_chunk=W["chunk"])
+
+    def gen():
+        forced = wl["forced"]
+        mlt = max(2, -(-len(forced) // wl["input_ids"].shape[1]) + 1)
+        return model.generate(input_ids=wl["input_ids"], tokenizer=wl["tok"], cfg_scale=args.cfg_scale, forced_tokens=forced, noise=wl["noise"],
+                              generation_config={"do_sample": False}, show_progress_bar=False, max_length_times=mlt,
+                              speech_tensors=wl["speech_tensors"], speech_masks=wl["speech_masks"], speech_input_mask=wl["speech_input_mask"],
+                              speech_noise=wl["speech_noise"], **gen_kw)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -311,13 +469,13 @@ def main():
     out = None
     for i in range(args.warmup):
         tw = time.perf_counter()
-        out = run_generate(model, wl, args.cfg_scale)
+        out = gen()
         torch.cuda.synchronize()
         log(f"warmup {i}: {time.perf_counter() - tw:.2f} s")
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run_generate(model, wl, args.cfg_scale)
+        out = gen()
         if dist is not None:
             vd.gather_waveforms(out.speech_outputs[0], dst=0)
     sync_all()
@@ -336,60 +494,76 @@ def main():
     result = None
     if rank == 0:
         L0 = wl["input_ids"].shape[1]
-        mean_ctx = L0 + args.frames / 2
+        mean_ctx = L0 + len(wl["forced"]) / 2
         wb = 2 if dtype == torch.bfloat16 else 4
         bpf, bpf_res, _ = bytes_per_frame(cfg, args.ddpm_steps, mean_ctx, wb)
         s_per_frame = dt / (args.steps * args.frames)
         result = {
             "metric": "audio-sec/s", "value": round(value, 4), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, seeded prompt/voice/noise, forced token schedule)",
-            "config": {"workload": f"VibeVoice-{args.model.upper()} shapes, 1 speaker, {args.voice_frames}-frame voice prompt, "
-                                   f"{L0}-token prompt, {args.frames} frames ({audio_s:.1f} s audio), CFG={args.cfg_scale}, "
-                                   f"{args.ddpm_steps} DPM-Solver++ steps, whole generate() incl. voice encode + prefill",
+            "vs_baseline": None, "dtype": args.dtype if not W["quant"] else f"{args.dtype} activations / fp8 e4m3 decode weights",
+            "data": "synthetic (random-init weights, seeded prompt/voice/noise, forced token schedule)",
+            "config": {"workload": f"{args.workload}: VibeVoice-{args.model.upper()} shapes, {W['speakers']} speaker(s) x {args.voice_frames}-frame voice prompt, "
+                                   f"{L0}-token prompt, {args.frames} frames ({audio_s:.1f} s audio)"
+                                   + (f", speech_end/speech_start every {W['turn']} frames" if W["turn"] else "") +
+                                   f", CFG={args.cfg_scale}, {args.ddpm_steps} DPM-Solver++ steps, whole generate() incl. voice encode + prefill"
+                                   + (f" in {W['chunk']}-token chunks" if W["chunk"] != 1024 else ""),
                        "global_batch": world, "parallelism": f"replicas x{world} (one dialogue per GPU)", "hipgraph": not args.no_graphs},
             "frame": {"ms_per_frame_incl_prefill": round(1e3 * s_per_frame, 4), "algorithmic_GB_per_frame": round(bpf / 1e9, 4),
                       "achieved_GBps": round(bpf / s_per_frame / 1e9, 1), "frac_of_hbm_peak": round(bpf / s_per_frame / 1e9 / HBM_PEAK_GBS, 4),
-                      "frac_if_head_weights_counted_once": round(bpf_res / s_per_frame / 1e9 / HBM_PEAK_GBS, 4)},
+                      "frac_if_head_weights_counted_once": round(bpf_res / s_per_frame / 1e9 / HBM_PEAK_GBS, 4),
+                      "note": "whole-frame HBM figure: the diffusion head's weights stay in the 256 MB Infinity Cache across solver steps, so "
+                              "frac_if_head_weights_counted_once is the honest HBM utilisation"},
         }
-    single = world == 1            # the diagnostic legs run at N = 1 only (other ranks would just wait at the final barrier)
     if rank == 0 and single:
-        result["first_chunk_latency"] = first_chunk_leg(model, wl, args.cfg_scale)
+        result["first_chunk_latency"] = first_chunk_leg(model, wl, args.cfg_scale, runs=args.first_chunk_runs, gen_kw=gen_kw)
         log(f"first-chunk latency p50 {result['first_chunk_latency']['p50_ms']} ms")
+        try:
+            result["first_chunk_latency"]["matrix_core_legs"] = first_chunk_parts(model, wl, cfg)
+        except Exception as e:      # noqa: BLE001
+            result["first_chunk_latency"]["matrix_core_legs"] = {"error": repr(e)}
     if rank == 0 and single and not args.no_roofline:
         ents = roofline_leg(model, wl, args.cfg_scale)
         log("roofline leg done")
-        top = ents[0]
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                with open(tp) as f:
-                    traffic = json.load(f).get(f"{top['m']}x{top['n']}x{top['k']}")
-            except Exception:
-                traffic = None
-        result["roofline"] = {"bound": "hbm", "kernel": f"gemv_stream_kernel (vv_linear m={top['m']} n={top['n']} k={top['k']} dual={top['dual']})",
-                              "achieved": round(top["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(top["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                              "avg_us": round(top["avg_us"], 2), "bytes_per_launch": top["weight_bytes"], "launches": top["count"]}
+        D, F = cfg.head_hidden, cfg.head_ffn
+        head_shapes = {(2, F, D), (2, D, F), (2, cfg.latent, D)}          # re-read by every solver step: served from the Infinity Cache
+
+        def entry(e):
+            cached = (e["m"], e["n"], e["k"]) in head_shapes
+            traffic, tnote = pmc_traffic(f"{e['m']}x{e['n']}x{e['k']}")
+            return {"bound": "hbm", "kernel": f"gemv_stream_kernel (vv_linear m={e['m']} n={e['n']} k={e['k']} dual={e['dual']})",
+                    "achieved": round(e["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_note": tnote, "avg_us": round(e["avg_us"], 2), "bytes_per_launch": e["weight_bytes"], "launches": e["count"],
+                    "served_from": "infinity cache (weights re-read by every solver step; HBM sees them once per frame)" if cached else "hbm",
+                    "timing": "HIP events on the launch stream around every eager launch of the timed frames (includes ~2-3 us of eager launch overhead "
+                              "a graph replay does not pay; profiles/r02_per_shape.csv has the in-graph durations)"}
+        result["roofline"] = entry(ents[0])
+        hbm_ents = [e for e in ents if (e["m"], e["n"], e["k"]) not in head_shapes]
+        if hbm_ents:
+            result["roofline_hbm_stream"] = entry(hbm_ents[0])
         result["kernels"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in e.items()} for e in ents[:8]]
     # the extra legs never take the headline line down with them
-    if rank == 0 and single and args.concurrent > 1:
+    if rank == 0 and single and headline and args.concurrent > 1:
         try:
-            result["concurrent_streams"] = concurrent_leg(model, cfg, model._bench_sd_all, dtype, device, args, args.concurrent)
+            result["concurrent_streams"] = concurrent_leg(model, cfg, sd, dtype, device, args, args.concurrent)
             log(f"concurrent x{args.concurrent}: {result['concurrent_streams']['value']} audio-sec/s aggregate")
         except Exception as e:      # noqa: BLE001
             result["concurrent_streams"] = {"error": repr(e)}
             log(f"concurrent leg failed: {e!r}")
-    if rank == 0 and single and args.fp8_leg and dtype == torch.bfloat16 and model._bench_sd_all is not None:
+    if rank == 0 and single and headline and args.fp8_leg and dtype == torch.bfloat16 and sd is not None:
         try:
-            result["fp8_weights"] = fp8_leg(cfg, model._bench_sd_all, device, args, wl)
+            result["fp8_weights"] = fp8_leg(cfg, sd, device, args, wl)
             log(f"fp8 weights: {result['fp8_weights']['value']} audio-sec/s")
         except Exception as e:      # noqa: BLE001
             result["fp8_weights"] = {"error": repr(e)}
             log(f"fp8 leg failed: {e!r}")
     if rank == 0 and single and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline_leg(model, cfg, args.cfg_scale, args.ddpm_steps)
+        if sd is None or args.model != "1.5b":
+            cfg15 = VVConfig.preset("1.5b")
+            sd15 = synth_state_dict_torch(cfg15, 1234, device=device, dtype=dtype)
+        else:
+            cfg15, sd15 = cfg, sd
+        result["cpu_baseline"] = cpu_baseline_leg(sd15, cfg15)
         log("cpu baseline done")
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 512 : 64 * KSPLIT) void gemv_stream_k
   // started once the first weights had landed: +2 us on every kernel with a prologue, +4 us on the dual one.)
   // the SwiGLU (dual) kernels take the block-staged prologue, the others the per-wave batched one: one fast path per instantiation
   // keeps the register allocation of each kernel at what its own path needs
-  constexpr bool CAN_STAGE = KSPLIT == 1 && DUAL;
+  constexpr bool CAN_STAGE = KSPLIT == 1 && (DUAL || M == 8);    // M = 8 (the T = 8 conv stage): 32 KB of activations per WAVE otherwise
   constexpr bool BATCHED = (M * KU <= 8) && !CAN_STAGE;
   // adaLN-modulated rows on a non-dual kernel (the head's 64-row final linear) keep the legacy path: the batch would pin 96 more registers
   const bool batched = BATCHED && ((a.pro == VV_PRO_RMSNORM && !a.mod_scale && (opt & 1)) || (a.pro == VV_PRO_NONE && (opt & 2)));

@@ -251,6 +251,7 @@ class VibeVoiceForConditionalGenerationInference:
         refresh_negative = kwargs.get("refresh_negative", True)
         if not refresh_negative:
             raise NotImplementedError("refresh_negative=False is not built (every reference caller passes True / default)")
+        self._prefill_chunk = int(kwargs.get("prefill_chunk", 1024))   # extension: rows per prefill launch sequence (cfg 5: 512-token chunks)
         forced_tokens = kwargs.get("forced_tokens")          # extension: bench / fixtures drive the token schedule
         noise = kwargs.get("noise")                          # extension: injected diffusion noise [F, latent]
         speech_noise = kwargs.get("speech_noise")            # extension: (std_noise [S], eps_noise [S, F, 64])
@@ -359,7 +360,7 @@ class VibeVoiceForConditionalGenerationInference:
             forced = forced_tokens[step] if (forced_tokens is not None and step < len(forced_tokens)) else None
             speculated = False
             if step == 0:
-                eng.prefill(x0, row=0, pos0=0)
+                eng.prefill(x0, row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024))
                 tok = eng.first_token(ST, SD, forced, sample_fn)
                 if tok == SD:
                     # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
