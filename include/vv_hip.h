@@ -101,6 +101,9 @@ typedef struct vv_kv {
   void* k;
   void* v;
   int kvdt, layers, rows, kv_heads, s_max, head_dim;
+  void* vt;   /* optional transposed value cache [layers][rows][kv_heads][head_dim][s_max] (same dtype): vv_rope_store keeps it in step with v
+                 for the rows it stores, and prompt-sized vv_attn calls (bf16, head_dim 128, s_max % 32 == 0) then run both attention products on
+                 the matrix cores without a transpose; NULL: the VALU kernels.  The decode step (vv_attn_decode) neither reads nor writes it. */
 } vv_kv;
 
 /* rope_table[R][head_dim/2][2] = {cos, sin}(lens[r] * inv_freq[i]): computed once per step, shared by all layers */

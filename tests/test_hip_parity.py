@@ -685,3 +685,42 @@ def test_prompt_attention_vs_torch(lib, heads, kv_heads, d, kvdt, R, pos0):
         sc = sc.masked_fill(mask, float("-inf"))
         want[:, h] = torch.softmax(sc, -1) @ vh
     assert rel_rms(out.cpu().numpy(), want.reshape(R, -1).numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("heads,kv_heads,R,pos0", [(12, 2, 77, 0), (28, 4, 40, 3), (12, 2, 330, 0), (12, 2, 64, 500), (4, 2, 33, 130), (12, 2, 16, 0)])
+def test_prompt_attention_matrix_core_vs_torch(lib, heads, kv_heads, R, pos0):
+    """vv_attn with a transposed value cache (vv_kv.vt): QK^T and PV on mfma_f32_32x32x16_bf16, one wave per (32-query tile, q head), causal
+    (row r sees keys 0..pos0+r), ragged last tile, a second chunk on top of 500 cached keys, GQA 6 / 7 / 2.  Q and P are rounded to bf16 for
+    the matrix cores (as FlashAttention-2 in the reference's bf16 run does): 5e-3 against a torch fp32 softmax on the same cache contents."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(heads * 100 + R + pos0)
+    d, layers, rows, layer = 128, 2, 2, 1
+    s_max = (pos0 + R + 3 + 31) // 32 * 32
+    kc = torch.randn(layers, rows, kv_heads, s_max, d, generator=g).to(torch.bfloat16)
+    vc = torch.randn(layers, rows, kv_heads, s_max, d, generator=g).to(torch.bfloat16)
+    ld = (heads + 2 * kv_heads) * d
+    qkv = torch.randn(R, ld, generator=g)
+    lens = torch.arange(pos0, pos0 + R, dtype=torch.int32)
+    crow = torch.ones(R, dtype=torch.int32)
+    kd, vd, vtd, qd, ld_, cd = kc.cuda(), vc.cuda(), vc.transpose(-1, -2).contiguous().cuda(), qkv.cuda(), lens.cuda(), crow.cuda()
+    out = torch.full((R, heads * d), float("nan"), device="cuda")
+    kv = L.KV(kd.data_ptr(), vd.data_ptr(), L.VV_BF16, layers, rows, kv_heads, s_max, d, vtd.data_ptr())
+    L.check(l.vv_attn(qd.data_ptr(), ld, R, heads, C.byref(kv), layer, ld_.data_ptr(), cd.data_ptr(), out.data_ptr(), heads * d, None), "vv_attn")
+    torch.cuda.synchronize()
+    q = qkv[:, :heads * d].view(R, heads, d)
+    want = torch.empty(R, heads, d)
+    for h in range(heads):
+        kh = kc[layer, 1, h // (heads // kv_heads)].float()
+        vh = vc[layer, 1, h // (heads // kv_heads)].float()
+        sc = (q[:, h] @ kh.T) / d ** 0.5
+        sc = sc.masked_fill(torch.arange(s_max)[None, :] > lens[:, None], float("-inf"))
+        want[:, h] = torch.softmax(sc, -1) @ vh
+    err = rel_rms(out.cpu().numpy(), want.reshape(R, -1).numpy())
+    assert err < 5e-3, f"matrix-core prompt attention vs torch: rel RMS {err:.3e}"
+    # the VALU kernels on the same inputs (vt = NULL) agree with the matrix-core path to bf16 rounding of Q / P
+    kv2 = L.KV(kd.data_ptr(), vd.data_ptr(), L.VV_BF16, layers, rows, kv_heads, s_max, d)
+    out2 = torch.empty_like(out)
+    L.check(l.vv_attn(qd.data_ptr(), ld, R, heads, C.byref(kv2), layer, ld_.data_ptr(), cd.data_ptr(), out2.data_ptr(), heads * d, None), "vv_attn")
+    torch.cuda.synchronize()
+    assert rel_rms(out.cpu().numpy(), out2.cpu().numpy()) < 5e-3

@@ -225,10 +225,11 @@ def test_streamer_threaded():
     assert st.finished_flags == [True, True]
 
 
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, bcast="broadcast"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["VV_BCAST"] = bcast
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vibevoice_rocm_amd import distributed as vd
     from vibevoice_rocm_amd.config import VVConfig
@@ -261,3 +262,21 @@ def test_sharding_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, True, [0, 2, 4]), (1, True, [1, 3])]
+
+
+def test_sharding_world3_scatter_allgather_gloo():
+    """The scatter + all-gather form of the checkpoint broadcast (VV_BCAST=scatter_allgather: the root sends 1/N of each blob to every
+    peer, the peers exchange the pieces) on three gloo ranks: every rank ends with the exact state dict; ragged waveform gather; 7
+    dialogues sharded 3 / 2 / 2."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 3, port, q, "scatter_allgather")) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True), (2, True)]
+    assert [it for _, _, it in res] == [[0, 3], [1, 4], [2]]

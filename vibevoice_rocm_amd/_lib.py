@@ -36,7 +36,7 @@ class LinArgs(C.Structure):
 
 class KV(C.Structure):
     _fields_ = [("k", vp), ("v", vp), ("kvdt", C.c_int), ("layers", C.c_int), ("rows", C.c_int),
-                ("kv_heads", C.c_int), ("s_max", C.c_int), ("head_dim", C.c_int)]
+                ("kv_heads", C.c_int), ("s_max", C.c_int), ("head_dim", C.c_int), ("vt", vp)]
 
 
 class LlmLayer(C.Structure):

@@ -49,6 +49,9 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
                           int64_t ldo, float* part, int* tickets, int nsplit, hipStream_t s);
 int vv_attn_decode_ws(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table, const int* lens, float* out,
                       int64_t ldo, float* part, int* tickets, int nsplit, vv_stream_t stream);
+// vv_attn_prefill.hip: matrix-core prompt attention (bf16 cache + kv->vt, head_dim 128); 1 launched, 0 not covered, < 0 error
+int vv_launch_attn_prefill(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const int* lens, const int* cache_rows,
+                           float* out, int64_t ldo, hipStream_t s);
 // vv_fused.hip
 int vv_head_init_fused(const vv_head* h, const float* noise, float* Xs, float* Ms, float* h0, int64_t ldh, hipStream_t s);
 bool vv_head_boundary_supported(const vv_head* h);

@@ -677,9 +677,11 @@ __global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int64_t ld,
     }
   }
   const float* vrow = row + (heads + kv.kv_heads) * d;
+  KT* vtc = reinterpret_cast<KT*>(kv.vt);                   // optional transposed copy [.., d, s_max] for the matrix-core prompt attention
   for (int idx = threadIdx.x; idx < kv.kv_heads * d; idx += blockDim.x) {
     const int h = idx / d, i = idx - h * d;
     kv_store<KT>(vc + base + ((int64_t)h * kv.s_max + pos) * d + i, vrow[idx]);
+    if (vtc) kv_store<KT>(vtc + base + ((int64_t)h * d + i) * kv.s_max + pos, vrow[idx]);
   }
 }
 
@@ -932,6 +934,10 @@ extern "C" int vv_attn(const float* qkv, int64_t ld_qkv, int R, int heads, const
   const size_t lds = (size_t)ng * (d + 2) * sizeof(float);
   if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn: LDS %zu too large", lds);
   hipStream_t s = (hipStream_t)stream;
+  {   // prompt rows against a bf16 cache with a transposed value copy: both products on the matrix cores (vv_attn_prefill.hip)
+    const int rc = vv_launch_attn_prefill(qkv, ld_qkv, R, heads, kv, layer, lens, cache_rows, out, ldo, s);
+    if (rc) return rc < 0 ? rc : 0;
+  }
   if (g_attn_group && R >= 8 && ((uintptr_t)qkv % 16 == 0) && (ld_qkv % 4 == 0)) {      // prompt-sized row counts: share K/V loads across the GQA group
     const int nq = heads / kv->kv_heads;
     bool done = false;

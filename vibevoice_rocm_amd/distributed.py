@@ -4,7 +4,8 @@ no collective inside the generation loop.  Two collectives exist, both outside t
     weight dtype, vectors in fp32): two large collectives instead of ~800 small ones.  Default: one RCCL broadcast per
     blob.  Opt-in (`VV_BCAST=scatter_allgather`): scatter + all-gather, where on a fully connected xGMI node the root
     pushes 1/N of the blob down each of its links and the peers exchange the pieces over theirs instead of a ring-bound
-    broadcast (7 links x ~153 GB/s per GPU, point to point) - not yet measured on an 8-GPU node, hence not the default.
+    broadcast (7 links x ~153 GB/s per GPU, point to point) - not yet measured on an 8-GPU node, hence not the default;
+    exercised on CPU by a world-size-3 gloo test.
   * `gather_waveforms`      ragged gather of the generated fp32 waveforms to `dst`.
 The backend is whatever the process group was created with: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 `shard_items` is the dialogue -> rank assignment (dialogue i -> rank i mod world).
@@ -47,17 +48,21 @@ def _padded(n: int) -> int:
 
 
 def _broadcast_flat(flat: torch.Tensor, src: int):
-    """In-place broadcast of a 1-D tensor whose length is a multiple of the world size: scatter + all-gather."""
+    """In-place broadcast of a 1-D tensor whose length is a multiple of the world size.  VV_BCAST=scatter_allgather selects the
+    scatter + all-gather form on any backend and world size >= 2 (the gloo tests drive it on CPU); default: one broadcast."""
     import os
     world = dist.get_world_size()
-    if world <= 2 or dist.get_backend() == "gloo" or os.environ.get("VV_BCAST", "broadcast") != "scatter_allgather":
+    if world < 2 or os.environ.get("VV_BCAST", "broadcast") != "scatter_allgather":
         dist.broadcast(flat, src=src)
         return
     chunk = flat.numel() // world
     mine = torch.empty(chunk, dtype=flat.dtype, device=flat.device)
-    parts = list(flat.split(chunk)) if dist.get_rank() == src else None
+    parts = [p.contiguous() for p in flat.split(chunk)] if dist.get_rank() == src else None
     dist.scatter(mine, parts, src=src)
-    dist.all_gather_into_tensor(flat, mine)
+    if dist.get_backend() == "gloo":        # no all_gather_into_tensor on gloo: gather into the chunk views of the flat buffer
+        dist.all_gather(list(flat.split(chunk)), mine)
+    else:
+        dist.all_gather_into_tensor(flat, mine)
 
 
 def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], cfg: VVConfig, dtype: torch.dtype, device, src: int = 0):
