@@ -312,3 +312,43 @@ def test_do_sample_constrained_vocabulary(big):
     cold = m.generate(input_ids=ids[None], tokenizer=tok, cfg_scale=1.3, generation_config={"do_sample": True, "temperature": 1e-4},
                       max_new_tokens=6, noise=torch.zeros(6, cfg.latent))
     assert cold.sequences.tolist() == greedy.sequences.tolist()
+
+
+def test_batch_of_four_lockstep_equals_singles_and_interleaves_streams(big):
+    """generate() on a batch of 4 left-padded dialogues with different token schedules (one ends early, one switches turns) runs in lock
+    step on one engine per sample: every sample's waveform and sequence equal its own single run BIT FOR BIT (same kernels, injected
+    noise), and an AudioStreamer receives the chunks of all diffusing samples once per step, interleaved, as the reference's batched loop
+    delivers them (modeling_vibevoice_inference.py:644-653), not sample after sample."""
+    from vibevoice_rocm_amd.streamer import AudioStreamer
+    cfg, sd, m = big
+    tok = _Tok(cfg.vocab)
+    D, E, S, EOS = tok.speech_diffusion_id, tok.speech_end_id, tok.speech_start_id, tok.eos_token_id
+    g = torch.Generator().manual_seed(31)
+    lens = [50, 37, 44, 29]
+    prompts = [torch.cat([torch.randint(0, 1000, (n - 1,), generator=g), torch.tensor([S])]) for n in lens]
+    Lp = max(lens)
+    ids = torch.stack([torch.cat([torch.full((Lp - n,), tok.pad_id), p]) for n, p in zip(lens, prompts)])
+    mask = torch.stack([torch.cat([torch.zeros(Lp - n, dtype=torch.long), torch.ones(n, dtype=torch.long)]) for n in lens])
+    forced = [[D] * 6 + [E, EOS], [D] * 2 + [E, EOS], [D] * 3 + [E, S] + [D] * 2 + [E, EOS], [D] * 5 + [E, EOS]]
+    noise = torch.randn(4, 8, cfg.latent, generator=g)
+    st = AudioStreamer(batch_size=4)
+    events = []
+    put0 = st.put
+
+    def spy(chunks, idx):
+        events.append([int(i) for i in idx])
+        put0(chunks, idx)
+    st.put = spy
+    out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise, audio_streamer=st)
+    assert len(m._lanes) >= 4
+    for b in range(4):
+        one = m.generate(input_ids=prompts[b][None], tokenizer=tok, cfg_scale=2.0, forced_tokens=forced[b], noise=noise[b])
+        assert torch.equal(out.speech_outputs[b], one.speech_outputs[0]), f"sample {b}: batch of 4 differs from its single run"
+        n_new = len(forced[b])
+        assert out.sequences[b, Lp: Lp + n_new].tolist() == forced[b]
+        assert out.sequences[b, : Lp - lens[b]].tolist() == [tok.pad_id] * (Lp - lens[b])
+        got = torch.cat([c.reshape(-1) for c in st.get_stream(b)])
+        assert torch.equal(got, one.speech_outputs[0][0].cpu()), f"sample {b}: streamed chunks"
+    # per-step interleave: the first two steps deliver all four samples together, later steps only the samples still in a speech segment
+    assert events[0] == [0, 1, 2, 3] and events[1] == [0, 1, 2, 3] and events[2] == [0, 2, 3]
+    assert st.finished_flags == [True] * 4 and not bool(out.reach_max_step_sample.any())

@@ -396,6 +396,23 @@ class Engine:
         self._tok_event.synchronize()
         return int(self.token_host[0])
 
+    def decode_begin(self, tok_start: int, tok_diff: int, forced: Optional[int], spec_noise=None):
+        """Lock-step batches (one Engine per sample, one host loop): enqueue phase A - and, with `spec_noise` = (noise, sde_noise), the
+        speculative phase B behind it - without waiting; `decode_end` returns the token."""
+        with torch.cuda.stream(self.stream):
+            self.forced_host[0] = -1 if forced is None else int(forced)
+            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._run("A", self._seq_A, int(tok_start), int(tok_diff))
+            self.token_host.copy_(self.token_dev, non_blocking=True)
+            self._tok_event.record(self.stream)
+            if spec_noise is not None:
+                self._upload_noise(*spec_noise)
+                self._run("B", self._seq_B, float(self.cfg_scale))
+
+    def decode_end(self) -> int:
+        self._tok_event.synchronize()
+        return int(self.token_host[0])
+
     def stage_chunk(self) -> int:
         """Enqueue the async D2H copy of the frame just generated into the next ring slot; returns the slot."""
         k = self._ring_n % len(self._ring)

@@ -140,6 +140,11 @@ class VibeVoiceForConditionalGenerationInference:
         self.weight_quant = weight_quant
         self.engine = Engine(config, state_dict, device=device, dtype=torch_dtype, use_graphs=use_graphs, weight_quant=weight_quant)
         self.device = self.engine.device
+        # batches run in lock step on one Engine per sample (own HIP stream, KV cache and conv state; matrices already in the streamed
+        # dtype on the device are shared, not copied): lanes beyond the first are built on first use from this state dict
+        self._state_dict = state_dict
+        self._lanes = [self.engine]
+        self._use_graphs = use_graphs
         self.ddpm_inference_steps = config.ddpm_infer
         # attribute paths the reference's callers read
         lm_cfg = SimpleNamespace(_attn_implementation=attn_implementation, hidden_size=config.hidden,
@@ -272,6 +277,10 @@ class VibeVoiceForConditionalGenerationInference:
         if speech_tensors is not None and speech_masks is not None:
             sn = speech_noise or (None, None)
             _, conn_all = self._process_speech_inputs(torch.as_tensor(speech_tensors).float(), torch.as_tensor(speech_masks).bool(), *sn)
+        if B > 1:
+            return self._generate_lockstep(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
+                                           forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
+                                           audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev)
         seqs, audios, reach = [], [], []
         off = 0
         for b in range(B):
@@ -300,6 +309,196 @@ class VibeVoiceForConditionalGenerationInference:
         seq_t = torch.full((B, mx), int(pad_id), dtype=torch.long)
         for b, s in enumerate(seqs):
             seq_t[b, : s.shape[0]] = s
+        return VibeVoiceGenerationOutput(sequences=seq_t.to(in_dev), speech_outputs=audios if return_speech else None,
+                                         reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
+
+
+    # ---- batches: lock step over samples (modeling_vibevoice_inference.py:430-673 with batch_size > 1) ---------------------
+    def _lane(self, b: int) -> Engine:
+        while len(self._lanes) <= b:
+            eng = Engine(self.config, self._state_dict, device=self.device, dtype=self.dtype, use_graphs=self._use_graphs, weight_quant=self.weight_quant)
+            eng.scheduler = self.engine.scheduler
+            self._lanes.append(eng)
+        eng = self._lanes[b]
+        if eng.scheduler is not self.engine.scheduler or eng.n_steps != self.engine.n_steps:
+            eng.scheduler = self.engine.scheduler
+            eng.set_steps(self.engine.n_steps)
+        return eng
+
+    def _generate_lockstep(self, input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
+                           forced_tokens, noise, sde_noise, audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev):
+        """One host loop drives B engines in lock step, as the reference's batched generate() does: every live sample takes its LLM step
+        (phase A of all of them is enqueued before any token is awaited, so the B dependent chains fill each other's bubbles on the GPU),
+        tokens are handled per sample (:517-563), the samples that emitted speech_diffusion are sampled / decoded / re-embedded (:571-670)
+        and their chunks reach the AudioStreamer together, once per step (:644-653).  A sample is the same computation as in a batch of
+        one - bit for bit with injected noise; the random draws follow the reference's order (randn(2 n, latent) per step for the n
+        diffusing samples, rows [:n] used, :699).  `forced_tokens` / `noise` / `sde_noise` may be given per sample (list / leading batch
+        dimension) or once for all."""
+        cfg = self.config
+        B, Lp = input_ids.shape
+        ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
+        valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
+        lanes = [self._lane(b) for b in range(B)]
+        for e in lanes[1:]:
+            e.sync_in()
+        keep = attention_mask.bool()
+        L0 = keep.sum(-1).tolist()
+        max_length = cfg.max_pos if max_new_tokens is None else Lp + int(max_new_tokens)            # :370-371 (padded length, as the reference)
+        max_steps = min(max_length - Lp, int(max_length_times * Lp))                                # :420
+        max_step_per_sample = [min(max_length - l, int(max_length_times * l)) for l in L0]          # :421
+        per_list = forced_tokens is not None and len(forced_tokens) > 0 and isinstance(forced_tokens[0], (list, tuple))
+        ftok = [(forced_tokens[b] if per_list else forced_tokens) for b in range(B)]
+        nz = [(noise[b] if (noise is not None and noise.dim() == 3) else noise) for b in range(B)]
+        snz = [(sde_noise[b] if (sde_noise is not None and sde_noise.dim() == 4) else sde_noise) for b in range(B)]
+        x0s, off = [], 0
+        for b in range(B):
+            eng = lanes[b]
+            ids_b = input_ids[b][keep[b]]
+            eng.cfg_scale = float(cfg_scale)
+            eng.begin_sequence(L0[b] + max(max_steps, 1) + 8, valid)
+            with torch.cuda.stream(eng.stream):
+                x0 = eng.embed_ids(ids_b)
+                if speech_input_mask is not None and conn_all is not None:
+                    sp_b = speech_input_mask[b][keep[b]].bool()
+                    n_b = int(sp_b.sum())
+                    if n_b:
+                        eng.stream.wait_stream(self.engine.stream)                                   # conn_all was produced on lane 0's stream
+                        x0[sp_b.to(self.device)] = conn_all[off: off + n_b]                         # :221-224
+                        off += n_b
+            x0s.append(x0)
+        seq = [input_ids[b][keep[b]].tolist() for b in range(B)]
+        chunks = [[] for _ in range(B)]
+        frame = [0] * B
+        finished = [False] * B
+        reach = [False] * B
+        prev_tok = [None] * B
+        pending = []                      # (sample, ring slot) of chunks not yet handed to the streamer
+        ours = [False] * max(B, getattr(audio_streamer, "batch_size", B) if audio_streamer is not None else B)   # streams ended by this loop
+        speculate = self.speculative_frames and sample_fn is None and self._use_graphs
+        sde = lanes[0].sde
+
+        def deliver():
+            if audio_streamer is None or not pending:
+                pending.clear()
+                return
+            idx = [b for b, _ in pending]
+            audio_streamer.put(torch.stack([lanes[b].take_chunk(k)[None] for b, k in pending]), torch.tensor(idx))   # one put per step, all samples (:644-653)
+            pending.clear()
+
+        def draw(n):
+            """the reference's draws for a step with n diffusing samples: randn(2 n, latent), rows [:n]; SDE: n_steps more of the same"""
+            a = torch.randn(2 * n, cfg.latent)[:n]
+            s_ = torch.stack([torch.randn(2 * n, cfg.latent)[:n] for _ in range(lanes[0].n_steps)], dim=1) if sde else None
+            return a, s_
+
+        for step in range(max_steps):
+            if stop_check_fn is not None and stop_check_fn():                                       # :432-438
+                if verbose:
+                    print(f"Generation stopped externally at step {step + 1}")
+                deliver()
+                if audio_streamer is not None:
+                    audio_streamer.end()
+                break
+            if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and \
+                    any(f and not ours[i] for i, f in enumerate(audio_streamer.finished_flags)):
+                break       # :441-445 "stopped externally".  Deviation, on purpose: the reference tests any(finished_flags), which its own
+                            # end(new_eos_indices) at :526 also sets - a batch with a streamer then stops at the FIRST sample's EOS; here
+                            # only streams ended by someone else stop the batch, streams this loop ended itself (EOS / max length) do not
+            if all(finished):
+                break
+            if Lp + step >= max_length:                                                             # :452-457
+                for b in range(B):
+                    reach[b] = reach[b] or not finished[b]
+                break
+            live = [b for b in range(B) if not finished[b]]
+            forced = {b: (ftok[b][step] if (ftok[b] is not None and step < len(ftok[b])) else None) for b in live}
+            toks = {}
+            speculated = set()
+            if step == 0:
+                for b in live:
+                    lanes[b].prefill(x0s[b], row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024))
+                for b in live:
+                    toks[b] = lanes[b].first_token(ST, SD, forced[b], sample_fn)
+                    if toks[b] == SD:
+                        lanes[b].prefill(lanes[b].embed_ids(torch.tensor([ST])), row=1, pos0=0)
+            elif sample_fn is not None:
+                for b in live:
+                    toks[b] = lanes[b].step_decode(ST, SD, forced[b], sample_fn)
+            else:
+                # phase A of every live sample goes out before any token is awaited; a sample in the steady state of a dialogue gets its
+                # diffusion tail enqueued speculatively behind it when its noise is injected (drawn noise depends on how many samples
+                # diffuse in this step, which is only known once the tokens are)
+                for b in live:
+                    spec = None
+                    if speculate and prev_tok[b] == SD and nz[b] is not None and frame[b] < len(nz[b]) and (not sde or (snz[b] is not None and frame[b] < len(snz[b]))):
+                        spec = (nz[b][frame[b]], snz[b][frame[b]] if sde else None)
+                        speculated.add(b)
+                    lanes[b].decode_begin(ST, SD, forced[b], spec)
+                deliver()                  # the previous step's chunks: their copies completed long before this step's tokens
+                for b in live:
+                    toks[b] = lanes[b].decode_end()
+            diffusing = []
+            for b in live:
+                tok = toks[b]
+                if b in speculated and tok != SD:
+                    lanes[b].rollback_speech_state()
+                prev_tok[b] = tok
+                seq[b].append(tok)
+                if tok == EOS:                                                                      # :517-526
+                    finished[b] = True
+                    if verbose:
+                        print(f"Samples [{b}] reached EOS token at step {step + 1}.", flush=True)
+                    if audio_streamer is not None:
+                        deliver()
+                        ours[b] = True
+                        audio_streamer.end(torch.tensor([b]))
+                    continue
+                if step >= max_step_per_sample[b]:                                                  # :528-537
+                    finished[b] = True
+                    reach[b] = True
+                    if audio_streamer is not None:
+                        deliver()
+                        ours[b] = True
+                        audio_streamer.end(torch.tensor([b]))
+                    continue
+                if tok == SE:                                                                       # :540-544
+                    with torch.cuda.stream(lanes[b].stream):
+                        lanes[b].reset_speech_caches()
+                if tok == SD:
+                    diffusing.append(b)
+                else:
+                    lanes[b].step_embed()                                                           # :567
+            need = [b for b in diffusing if b not in speculated and (nz[b] is None or frame[b] >= len(nz[b]))]
+            drawn = draw(len(need)) if need else None
+            for b in diffusing:                                                                     # :571-670
+                if b not in speculated:
+                    if b in need:
+                        i = need.index(b)
+                        n_row, s_row = drawn[0][i], (drawn[1][i] if sde else None)
+                    else:
+                        n_row, s_row = nz[b][frame[b]], (snz[b][frame[b]] if sde else None)
+                    lanes[b].step_speech(n_row, s_row)
+                with torch.cuda.stream(lanes[b].stream):
+                    chunks[b].append(lanes[b].wav.clone())
+                if audio_streamer is not None:
+                    pending.append((b, lanes[b].stage_chunk()))
+                frame[b] += 1
+        deliver()
+        for e in lanes[:B]:
+            e.stream.synchronize()
+        if audio_streamer is not None:
+            audio_streamer.end()
+        pad_id = getattr(tokenizer, "pad_id", None)
+        if pad_id is None:
+            pad_id = special["eos"]
+        rows = []
+        for b in range(B):
+            rows.append(torch.cat([input_ids[b][~keep[b]], torch.tensor(seq[b], dtype=torch.long)]))
+        mx = max(r.shape[0] for r in rows)
+        seq_t = torch.full((B, mx), int(pad_id), dtype=torch.long)
+        for b, r in enumerate(rows):
+            seq_t[b, : r.shape[0]] = r
+        audios = [(torch.cat(c)[None] if c else None) for c in chunks]
         return VibeVoiceGenerationOutput(sequences=seq_t.to(in_dev), speech_outputs=audios if return_speech else None,
                                          reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
 
