@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: one hardware queue per lane of the batched / concurrent legs
+
 import numpy as np
 import torch
 
@@ -263,8 +265,11 @@ def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
     """Serving-throughput extra (NOT the headline value): `streams` independent dialogues on ONE GPU, each with its own Engine,
     HIP stream and host thread, sharing the resident weights.  A single dialogue is a latency-bound chain of ~580 small
     kernels per frame, so a second and third chain fill the bubbles."""
+    import gc
     import threading
     from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    model._lanes = model._lanes[:1]          # lanes of an earlier batched leg hand their HIP streams back (engine.py, _IDLE_STREAMS)
+    gc.collect()
     models = [model] + [VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
                         for _ in range(streams - 1)]
     for mm in models:
@@ -286,9 +291,38 @@ def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
             t.join()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    del models, mm
+    gc.collect()               # the extra engines hand their HIP streams back for the next leg (engine.py, _IDLE_STREAMS)
     return dict(streams=streams, value=round(sum(outs) / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3),
                 note="aggregate over independent dialogues run concurrently on one GPU (one Engine/stream/thread each, shared weights); "
                      "not the headline metric, which is one dialogue per GPU")
+
+
+def batched_leg(model, cfg, args, batch=4):
+    """Extra (NOT the headline value): ONE generate() call on a batch of `batch` dialogues of the headline shape - the reference's own
+    batch dimension (modeling_vibevoice_inference.py:459-653).  The samples advance in lock step on one engine lane each (own HIP stream,
+    KV cache and conv state, shared weights), one host loop."""
+    wls = [build_workload(cfg, args.frames, args.voice_frames, seed=201 + i) for i in range(batch)]
+    ids = torch.cat([w["input_ids"] for w in wls])
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=wls[0]["tok"], cfg_scale=args.cfg_scale,
+              forced_tokens=[w["forced"] for w in wls], noise=torch.stack([w["noise"] for w in wls]),
+              speech_tensors=torch.cat([w["speech_tensors"] for w in wls]).to(model.engine.device),
+              speech_masks=torch.cat([w["speech_masks"] for w in wls]), speech_input_mask=torch.cat([w["speech_input_mask"] for w in wls]),
+              speech_noise=(torch.cat([w["speech_noise"][0] for w in wls]), torch.cat([w["speech_noise"][1] for w in wls])),
+              generation_config={"do_sample": False}, show_progress_bar=False,
+              max_length_times=max(2, -(-len(wls[0]["forced"]) // ids.shape[1]) + 1))
+    n, dt = 0, None
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.generate(**kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = sum(o.shape[-1] for o in out.speech_outputs)
+    assert n == batch * args.frames * cfg.hop, (n, batch, args.frames)
+    return dict(batch=batch, value=round(n / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3),
+                note="one generate() call on a batch of dialogues of the headline shape, samples in lock step on one engine lane each; "
+                     "aggregate audio seconds per wall second, not the headline metric (one dialogue per GPU)")
 
 
 def fp8_leg(cfg, sd, device, args, wl):
@@ -399,6 +433,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-fp8-leg", dest="fp8_leg", action="store_false", help="skip the extra weight-only-fp8 leg")
     ap.add_argument("--concurrent", type=int, default=3, help="extra leg: N independent dialogues concurrently on one GPU (0/1 = skip)")
+    ap.add_argument("--batched", type=int, default=4, help="extra leg: one generate() call on a batch of N dialogues (0/1 = skip)")
     ap.add_argument("--first-chunk-runs", type=int, default=5)
     args = ap.parse_args()
     W = WORKLOADS[args.workload]
@@ -543,6 +578,13 @@ def main():
             result["roofline_hbm_stream"] = entry(hbm_ents[0])
         result["kernels"] = [{k: (round(v, 2) if isinstance(v, float) else v) for k, v in e.items()} for e in ents[:8]]
     # the extra legs never take the headline line down with them
+    if rank == 0 and single and headline and args.batched > 1:
+        try:
+            result["batched_generate"] = batched_leg(model, cfg, args, args.batched)
+            log(f"batched x{args.batched}: {result['batched_generate']['value']} audio-sec/s aggregate")
+        except Exception as e:      # noqa: BLE001
+            result["batched_generate"] = {"error": repr(e)}
+            log(f"batched leg failed: {e!r}")
     if rank == 0 and single and headline and args.concurrent > 1:
         try:
             result["concurrent_streams"] = concurrent_leg(model, cfg, sd, dtype, device, args, args.concurrent)

@@ -352,3 +352,25 @@ def test_batch_of_four_lockstep_equals_singles_and_interleaves_streams(big):
     # per-step interleave: the first two steps deliver all four samples together, later steps only the samples still in a speech segment
     assert events[0] == [0, 1, 2, 3] and events[1] == [0, 1, 2, 3] and events[2] == [0, 2, 3]
     assert st.finished_flags == [True] * 4 and not bool(out.reach_max_step_sample.any())
+
+
+def test_batch_of_six_shares_streams_and_equals_singles(big):
+    """A batch larger than LANES_IN_FLIGHT: lanes 4 and 5 run on the HIP streams of lanes 0 and 1 (modeling._lane), queued behind
+    them by stream order.  Every sample still equals its own single run bit for bit, and no new streams were created."""
+    from vibevoice_rocm_amd import modeling as M
+    cfg, sd, m = big
+    tok = _Tok(cfg.vocab)
+    D, E, EOS, S = tok.speech_diffusion_id, tok.speech_end_id, tok.eos_token_id, tok.speech_start_id
+    g = torch.Generator().manual_seed(37)
+    B, L = 6, 40
+    ids = torch.stack([torch.cat([torch.randint(0, 1000, (L - 1,), generator=g), torch.tensor([S])]) for _ in range(B)])
+    forced = [[D] * (3 + (b % 3)) + [E, EOS] for b in range(B)]
+    noise = torch.randn(B, 5, cfg.latent, generator=g)
+    out = m.generate(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise)
+    assert len(m._lanes) >= B
+    streams = [e.stream.cuda_stream for e in m._lanes[:B]]
+    assert len(set(streams)) == M.LANES_IN_FLIGHT and streams[4] == streams[0] and streams[5] == streams[1]
+    for b in range(B):
+        one = m.generate(input_ids=ids[b][None], tokenizer=tok, cfg_scale=2.0, forced_tokens=forced[b], noise=noise[b])
+        assert torch.equal(out.speech_outputs[b], one.speech_outputs[0]), f"sample {b}: batch of 6 differs from its single run"
+        assert out.sequences[b, L: L + len(forced[b])].tolist() == forced[b]

@@ -25,10 +25,17 @@ from .schedule import DPMSolverMultistepScheduler, timestep_sinusoid
 from .weights import DeviceWeights
 
 
+# HIP streams an Engine gave back, per device.  Streams are recycled, never just dropped: every stream that has run work keeps a hardware
+# queue, and on MI355X a process with more than ~5 queues that have ever been active runs concurrent lanes 2-3x slower (measured:
+# batch-of-4 generate 69 -> 30 audio-s/s once three more streams had been used, tools/dbg_lanes.py), so the number of streams has to
+# stay at the number of engines alive at once.
+_IDLE_STREAMS: Dict[str, list] = {}
+
+
 class Engine:
     def __init__(self, cfg: VVConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", dtype=torch.bfloat16,
                  kv_dtype: Optional[torch.dtype] = None, use_graphs: bool = True, bf16_timestep_quirk: Optional[bool] = None,
-                 weight_quant: Optional[str] = None):
+                 weight_quant: Optional[str] = None, stream: Optional[torch.cuda.Stream] = None):
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -39,7 +46,11 @@ class Engine:
         self.use_graphs = use_graphs
         self.bf16_t_quirk = (dtype == torch.bfloat16) if bf16_timestep_quirk is None else bf16_timestep_quirk
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.Stream(self.device)
+        self._own_stream = stream is None
+        if stream is None:                               # `stream`: run on another engine's stream (lanes of a large lock-step batch)
+            idle = _IDLE_STREAMS.setdefault(str(self.device), [])
+            stream = idle.pop() if idle else torch.cuda.Stream(self.device)
+        self.stream = stream
         torch.zeros(1, device=self.device)              # make sure the HIP context exists before the library touches it
         L.check(self.lib.vv_init(), "vv_init")          # one-time kernel attributes, before any graph capture
         self.sync_in()
@@ -395,6 +406,14 @@ class Engine:
             on_enqueued()          # e.g. hand the previous frame's audio to the streamer: it completes before this step's token
         self._tok_event.synchronize()
         return int(self.token_host[0])
+
+    def __del__(self):
+        try:
+            if self._own_stream:
+                self.stream.synchronize()
+                _IDLE_STREAMS.setdefault(str(self.device), []).append(self.stream)
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def decode_begin(self, tok_start: int, tok_diff: int, forced: Optional[int], spec_noise=None):
         """Lock-step batches (one Engine per sample, one host loop): enqueue phase A - and, with `spec_noise` = (noise, sde_noise), the

@@ -26,6 +26,8 @@ from .config import VVConfig
 from .engine import Engine
 from .synth import state_dict_shapes
 
+LANES_IN_FLIGHT = 4       # lock-step batches: lanes (one HIP stream each) enqueued concurrently; see _generate_lockstep
+
 
 @dataclass
 class VibeVoiceGenerationOutput:
@@ -316,7 +318,9 @@ class VibeVoiceForConditionalGenerationInference:
     # ---- batches: lock step over samples (modeling_vibevoice_inference.py:430-673 with batch_size > 1) ---------------------
     def _lane(self, b: int) -> Engine:
         while len(self._lanes) <= b:
-            eng = Engine(self.config, self._state_dict, device=self.device, dtype=self.dtype, use_graphs=self._use_graphs, weight_quant=self.weight_quant)
+            n = len(self._lanes)             # lanes past LANES_IN_FLIGHT share the stream of lane n % LANES_IN_FLIGHT: see _generate_lockstep
+            eng = Engine(self.config, self._state_dict, device=self.device, dtype=self.dtype, use_graphs=self._use_graphs, weight_quant=self.weight_quant,
+                         stream=self._lanes[n % LANES_IN_FLIGHT].stream if n >= LANES_IN_FLIGHT else None)
             eng.scheduler = self.engine.scheduler
             self._lanes.append(eng)
         eng = self._lanes[b]
@@ -391,6 +395,10 @@ class VibeVoiceForConditionalGenerationInference:
             s_ = torch.stack([torch.randn(2 * n, cfg.latent)[:n] for _ in range(lanes[0].n_steps)], dim=1) if sde else None
             return a, s_
 
+        pool = None
+        if B > 1 and os.environ.get("VV_LANE_THREADS", "1") != "0":
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=min(B, LANES_IN_FLIGHT))
         for step in range(max_steps):
             if stop_check_fn is not None and stop_check_fn():                                       # :432-438
                 if verbose:
@@ -428,12 +436,27 @@ class VibeVoiceForConditionalGenerationInference:
                 # phase A of every live sample goes out before any token is awaited; a sample in the steady state of a dialogue gets its
                 # diffusion tail enqueued speculatively behind it when its noise is injected (drawn noise depends on how many samples
                 # diffuse in this step, which is only known once the tokens are)
+                specs = {}
                 for b in live:
-                    spec = None
+                    specs[b] = None
                     if speculate and prev_tok[b] == SD and nz[b] is not None and frame[b] < len(nz[b]) and (not sde or (snz[b] is not None and frame[b] < len(snz[b]))):
-                        spec = (nz[b][frame[b]], snz[b][frame[b]] if sde else None)
+                        specs[b] = (nz[b][frame[b]], snz[b][frame[b]] if sde else None)
                         speculated.add(b)
-                    lanes[b].decode_begin(ST, SD, forced[b], spec)
+                # a frame is ~600 graph nodes and the runtime enqueues them node by node: the lanes' launches go out from one host
+                # thread each (the HIP calls release the GIL), or the host becomes the bottleneck at batch > 2
+                # at most LANES_IN_FLIGHT lanes run at once: more streams than that serialise badly on MI355X (8 streams in flight are
+                # slower than 4), so lane b of a larger batch shares the HIP stream of lane b % LANES_IN_FLIGHT and stream order queues
+                # it behind that lane's frame.  One host thread per stream (never two threads on one stream: first use captures graphs).
+                def begin(s_):
+                    for b in live:
+                        if b % LANES_IN_FLIGHT == s_:
+                            lanes[b].decode_begin(ST, SD, forced[b], specs[b])
+                slots = sorted({b % LANES_IN_FLIGHT for b in live})
+                if pool is not None and len(slots) > 1:
+                    list(pool.map(begin, slots))
+                else:
+                    for s_ in slots:
+                        begin(s_)
                 deliver()                  # the previous step's chunks: their copies completed long before this step's tokens
                 for b in live:
                     toks[b] = lanes[b].decode_end()
@@ -484,6 +507,8 @@ class VibeVoiceForConditionalGenerationInference:
                     pending.append((b, lanes[b].stage_chunk()))
                 frame[b] += 1
         deliver()
+        if pool is not None:
+            pool.shutdown()
         for e in lanes[:B]:
             e.stream.synchronize()
         if audio_streamer is not None:
