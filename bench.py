@@ -84,8 +84,10 @@ def build_workload(cfg, frames, voice_frames, seed=1, speakers=1, text=88, turn=
                 speech_noise=speech_noise, tok=Tok(), special=dict(speech_start=ST, speech_end=SE, speech_diffusion=SD, eos=EOS))
 
 
-def bytes_per_frame(cfg, n_steps, mean_ctx, wbytes=2):
-    """b*(W_llm + N*W_head + W_dec + W_sem + W_conn) + 2*S*KVb + state."""
+def bytes_per_frame(cfg, n_steps, mean_ctx, wbytes=2, gemv_wbytes=None):
+    """b*(W_llm + N*W_head + W_dec + W_sem + W_conn) + 2*S*KVb + state.  gemv_wbytes: bytes per weight of the LLM and head
+    matrices when they stream as fp8 codes (weight_quant="fp8"; the adaLN matrices and norms stay bf16, counted at 1 byte here too: an
+    under-count of < 15 % of the head)."""
     from vibevoice_rocm_amd.synth import state_dict_shapes
     tot = dict(llm=0, head=0, dec=0, sem=0, conn=0)
     for n, s in state_dict_shapes(cfg).items():
@@ -101,8 +103,9 @@ def bytes_per_frame(cfg, n_steps, mean_ctx, wbytes=2):
         elif "_connector." in n:
             tot["conn"] += k
     kvb = cfg.layers * 2 * cfg.kv_heads * cfg.head_dim * wbytes
-    b = wbytes * (tot["llm"] + n_steps * tot["head"] + tot["dec"] + tot["sem"] + tot["conn"]) + 2 * mean_ctx * kvb
-    b_resident_head = wbytes * (tot["llm"] + tot["head"] + tot["dec"] + tot["sem"] + tot["conn"]) + 2 * mean_ctx * kvb
+    gw = gemv_wbytes or wbytes
+    b = gw * (tot["llm"] + n_steps * tot["head"]) + wbytes * (tot["dec"] + tot["sem"] + tot["conn"]) + 2 * mean_ctx * kvb
+    b_resident_head = gw * (tot["llm"] + tot["head"]) + wbytes * (tot["dec"] + tot["sem"] + tot["conn"]) + 2 * mean_ctx * kvb
     return b, b_resident_head, tot
 
 
@@ -141,7 +144,7 @@ def roofline_leg(model, wl, cfg_scale, frames=12):
         e = out[i]
         if e.m > 8:
             continue                                                                 # prefill GEMMs are not the per-frame path
-        wb = (2 if e.wdt == L.VV_BF16 else 4) * e.n * e.k * (2 if e.dual else 1)
+        wb = {L.VV_BF16: 2, L.VV_FP8: 1}.get(e.wdt, 4) * e.n * e.k * (2 if e.dual else 1)
         ents.append(dict(m=e.m, n=e.n, k=e.k, dual=bool(e.dual), count=e.count, total_ms=e.total_ms, avg_us=1e3 * e.total_ms / e.count,
                          weight_bytes=wb, gbs=wb / (e.total_ms / e.count * 1e-3) / 1e9))
     ents.sort(key=lambda d: -d["total_ms"])
@@ -531,7 +534,7 @@ def main():
         L0 = wl["input_ids"].shape[1]
         mean_ctx = L0 + len(wl["forced"]) / 2
         wb = 2 if dtype == torch.bfloat16 else 4
-        bpf, bpf_res, _ = bytes_per_frame(cfg, args.ddpm_steps, mean_ctx, wb)
+        bpf, bpf_res, _ = bytes_per_frame(cfg, args.ddpm_steps, mean_ctx, wb, 1 if (W["quant"] and dtype == torch.bfloat16) else None)
         s_per_frame = dt / (args.steps * args.frames)
         result = {
             "metric": "audio-sec/s", "value": round(value, 4), "unit": "audio-sec/s", "n_gpus": world, "steps": args.steps,
