@@ -251,6 +251,56 @@ def test_block1d_single_launch_vs_torch(lib, C_, T):
     assert l.vv_block1d(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), 8, C_, eps, None) != 0
 
 
+@pytest.mark.parametrize("C_,T", [(512, 40), (256, 200), (512, 37), (256, 5), (512, 64), (256, 256), (512, 3)])
+def test_block_mid_two_launches_vs_torch(lib, C_, T):
+    """vv_block_mid (middle-stage Block1D of a streaming frame as two launches: mixer + first FFN GEMM, second FFN GEMM; vv_convffn.hip)
+    against the torch fp32 restatement of Block1D.forward (modular_vibevoice_tokenizer.py:555-600) on the same bf16-rounded weights:
+    three consecutive streaming calls (history carried in b.hist, also when T < 6 keeps old history rows) and a stateless call, in place
+    and out of place.  Tolerance: activations are rounded to bf16 at the two GEMM inputs."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(300 + C_ + T)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    p = dict(gamma=r(C_, sc=0.5), ffn_gamma=r(C_, sc=0.5), norm_w=1 + r(C_, sc=0.1), ffn_norm_w=1 + r(C_, sc=0.1), dw_w=r(C_, 7, sc=0.3), dw_b=r(C_, sc=0.1),
+             w1=(r(4 * C_, C_) / C_ ** 0.5).bfloat16(), b1=r(4 * C_, sc=0.1), w2=(r(C_, 4 * C_) / (4 * C_) ** 0.5).bfloat16(), b2=r(C_, sc=0.1))
+    eps = 1e-5
+
+    def rms(x, w): return x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps) * w
+
+    def ref(x, hist):
+        xn = rms(x, p["norm_w"])
+        seq = torch.cat([hist, xn])
+        s = p["dw_b"] + sum(p["dw_w"][:, k] * seq[k: k + x.shape[0]] for k in range(7))
+        x1 = x + p["gamma"] * s
+        h = torch.nn.functional.gelu(rms(x1, p["ffn_norm_w"]) @ p["w1"].float().T + p["b1"])
+        return x1 + p["ffn_gamma"] * (h @ p["w2"].float().T + p["b2"]), seq[-6:]
+
+    d = {k: v.cuda().contiguous() for k, v in p.items()}
+    hist_dev = torch.zeros(6, C_, device="cuda")
+    b = L.Block()
+    for k in ("gamma", "ffn_gamma", "norm_w", "ffn_norm_w", "dw_w", "dw_b", "w1", "b1", "w2", "b2"):
+        setattr(b, k, d[k].data_ptr())
+    ws = torch.empty(l.vv_block_mid_ws_bytes(T, C_), dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(6, C_)
+    for call in range(4):                       # calls 0-2: streaming; call 3: stateless (zero left context)
+        x = r(T, C_)
+        streaming = call < 3
+        b.hist = hist_dev.data_ptr() if streaming else None
+        want, new_hist = ref(x, hist if streaming else torch.zeros(6, C_))
+        xd, od = x.cuda(), torch.full((T, C_), float("nan"), device="cuda")
+        L.check(l.vv_block_mid(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), ws.data_ptr(), T, C_, eps, None), "vv_block_mid")
+        torch.cuda.synchronize()
+        e = rel_rms(od.cpu().numpy(), want.numpy())
+        assert e < 1e-2, f"call {call} C={C_} T={T}: rel RMS {e:.3e}"
+        if streaming:
+            hist = new_hist
+            eh = rel_rms(hist_dev.cpu().numpy(), hist.numpy())
+            assert eh < 1e-5, f"call {call} C={C_} T={T}: history rel RMS {eh:.3e}"
+    # not covered -> explicit refusal, never a silent fallback
+    assert l.vv_block_mid(C.byref(b), L.VV_F32, xd.data_ptr(), od.data_ptr(), ws.data_ptr(), T, C_, eps, None) != 0
+    assert l.vv_block_mid(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), ws.data_ptr(), 2, C_, eps, None) != 0
+
+
 @pytest.mark.parametrize("m,n,k,dual", [(330, 2048, 1536, False), (200, 8960, 1536, True), (129, 1536, 8960, False), (128, 128, 32, False), (513, 256, 96, True),
                                         (1024, 256, 1024, False), (2500, 128, 512, False), (1300, 384, 96, True),
                                         (330, 1536, 8960, False), (203, 2048, 8192, False), (65, 3072, 2048, False), (203, 64, 14336, False), (64, 192, 8192, False)])

@@ -106,6 +106,8 @@ PROTOTYPES = {
     "vv_attn_decode": (C.c_int, [vp, i64, C.c_int, C.c_int, C.POINTER(KV), C.c_int, vp, vp, vp, i64, vp]),
     "vv_block_mixer": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp]),
     "vv_block1d": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "vv_block_mid_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vv_block_mid": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "vv_conv_ctx": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "vv_affine": (C.c_int, [vp, C.c_float, C.c_float, vp, i64, vp]),
     "vv_add_rows": (C.c_int, [vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -62,6 +62,10 @@ int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStre
 int vv_block1d_init();                                            // vv_block1d.hip
 int vv_launch_block1d(const vv_block& B, int wdt, const float* x, float* out, int T, int C, float eps, hipStream_t s);   // 1 launched, 0 not covered
 void vv_block1d_set_fused(int on);
+int vv_convffn_init();                                            // vv_convffn.hip
+int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, int C, float eps,
+                      hipStream_t s);                            // 1 launched, 0 not covered
+void vv_convffn_set(int on);
 int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s);
 
 #ifdef __HIPCC__

@@ -1,0 +1,321 @@
+// vv_convffn.hip — the middle stages of the streaming conv tokenizers (C = 256 / 512 channels, T = 200 / 40 rows per frame) as TWO
+// launches per Block1D instead of three, each a single global-memory round trip.
+//
+// Reference: Block1D.forward (vibevoice/modular/modular_vibevoice_tokenizer.py:555-600):
+//     y   = x + gamma     * (dwconv7_causal(RMSNorm(x)) + b)          (mixer)
+//     out = y + ffn_gamma * (W2 gelu(W1 RMSNorm(y) + b1) + b2)        (FFN, hidden width 4C)
+// At these sizes a frame holds a few hundred KB of activations against 1-4 MB of weights per block: every kernel is a latency
+// chain, not a bandwidth or FLOP problem.  The three-launch form (mixer, GEMM, GEMM on the general vv_linear kernels) spent
+// 24-39 us per block on ~1 us of work: each kernel made 3-5 DEPENDENT trips to L2 (row statistics, staging pass, weight batches,
+// epilogue parameters).  Here:
+//   ffn_in_kernel   grid (4C/32 hidden blocks, row tiles of 32): every workgroup requests its weight fragments, its per-channel
+//                   parameters and the 38-row window (6 halo rows) in ONE burst, then runs mixer -> RMSNorm -> bf16 image in LDS ->
+//                   MFMA (K split over the 4 waves) -> GELU -> bf16 hidden tile.  The mixer is recomputed by every hidden block
+//                   of a row tile (a few hundred FMAs per thread: cheaper than a launch); workgroup j writes columns
+//                   [8j, 8j + 8) of y, the last row tile's workgroup 0 the new streaming history (to a scratch row set: the
+//                   other workgroups may still be reading the old one).
+//   ffn_out_kernel  grid (C/16 output blocks, row tiles of 16) on mfma_f32_16x16x32_bf16: all weight and activation fragments of
+//                   a wave's K quarter are requested up front (<= 128 VGPRs), combine through LDS, out = y + ffn_gamma (. + b2).
+//                   Workgroup (0, 0) moves the scratch history into place.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "vv_hip.h"
+#include "vv_common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TR = 32;          // rows per workgroup of ffn_in (one 32 x 32 MFMA tile)
+constexpr int TR2 = 16;         // rows per workgroup of ffn_out (one 16 x 16 MFMA tile)
+constexpr int HALO = 6;         // causal depthwise kernel 7
+
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+  const __hip_bfloat16 x = __float2bfloat16(a), y = __float2bfloat16(b);
+  return (unsigned int)(*reinterpret_cast<const bf16_t*>(&x)) | ((unsigned int)(*reinterpret_cast<const bf16_t*>(&y)) << 16);
+}
+__device__ __forceinline__ float sq4(const float4 v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+
+template <int C> struct InLay {
+  static constexpr int F4 = C / 4;                        // float4 columns per row = threads per row
+  static constexpr int RP = 256 / F4;                     // window rows per pass of the 256 threads
+  static constexpr int NI = (TR + HALO + RP - 1) / RP;    // passes over the 38-row window
+  static constexpr int WPR = F4 / 64;                     // waves per row (partial sums of squares per row)
+  static constexpr int P1 = C + 8;                        // bf16 pitch of the FFN input image
+  static constexpr int ST = C / 64;                       // MFMA steps of one wave (K split over the 4 waves)
+  static constexpr size_t XN = (size_t)(TR + HALO) * C * 4;
+  static constexpr size_t RED = (size_t)4 * 16 * 64 * 4;  // K-split partial accumulators (alias the window once it is consumed)
+  static constexpr size_t XH = (size_t)TR * P1 * 2;
+  static constexpr size_t PART = (size_t)2 * (TR + HALO) * 4 * 4;
+  static constexpr size_t LDS = (XN > RED ? XN : RED) + XH + PART;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ hidden,
+                                                     float* __restrict__ hist_new, int T, const vv_block B, float eps) {
+  using L = InLay<C>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* xn = reinterpret_cast<float*>(smem);                                        // [TR + 6][C] normalised window
+  float* red = reinterpret_cast<float*>(smem);                                       // aliases xn after the conv
+  bf16_t* xh = reinterpret_cast<bf16_t*>(smem + (L::XN > L::RED ? L::XN : L::RED));  // [TR][P1] RMSNorm(y) in bf16
+  float* part = reinterpret_cast<float*>(smem + (L::XN > L::RED ? L::XN : L::RED) + L::XH);   // [2][TR + 6][4]
+  float* part2 = part + (TR + HALO) * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 32;
+  const int t0 = blockIdx.y * TR;
+  const int rows = min(TR, T - t0);
+  const int lm = lane & 31, hk = (lane >> 5) * 8;
+
+  // ---- everything this workgroup needs from memory, in one burst -------------------------------------------------------------
+  u32x4 wf[L::ST];
+  {
+    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w1) + (int64_t)(n0 + lm) * C + wave * (C / 4) + hk;
+#pragma unroll
+    for (int s = 0; s < L::ST; ++s) wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
+  }
+  const int cq = tid % L::F4, rloc = tid / L::F4, c0 = cq * 4;
+  const int slot = wave % L::WPR;
+  float4 own[L::NI];
+#pragma unroll
+  for (int i = 0; i < L::NI; ++i) {
+    const int w = rloc + L::RP * i, t = t0 - HALO + w;
+    own[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w < rows + HALO) {
+      if (t >= 0) own[i] = *reinterpret_cast<const float4*>(x + (int64_t)t * C + c0);
+      else if (B.hist) own[i] = *reinterpret_cast<const float4*>(B.hist + (int64_t)(HALO + t) * C + c0);     // already normalised
+    }
+  }
+  const float4 nw = *reinterpret_cast<const float4*>(B.norm_w + c0);
+  const float4 db = *reinterpret_cast<const float4*>(B.dw_b + c0);
+  const float4 gm = *reinterpret_cast<const float4*>(B.gamma + c0);
+  const float4 fw = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0);
+  float tap[28];                                                   // tap[7 c + k] of channels c0 .. c0 + 3
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float4 tq = *reinterpret_cast<const float4*>(B.dw_w + (size_t)c0 * 7 + 4 * q);
+    tap[4 * q] = tq.x; tap[4 * q + 1] = tq.y; tap[4 * q + 2] = tq.z; tap[4 * q + 3] = tq.w;
+  }
+  const int eg = tid >> 6;                                         // epilogue: this thread finishes channels n0 + 8 eg + 4 (lane >> 5) + {0..3}
+  const float4 b1v = *reinterpret_cast<const float4*>(B.b1 + n0 + 8 * eg + 4 * (lane >> 5));
+
+  // ---- 1. RMS statistic of the window rows ------------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < L::NI; ++i) {
+    const int w = rloc + L::RP * i;
+    const float s = vv_wave_sum(sq4(own[i]));
+    if (lane == 0 && w < TR + HALO) part[w * 4 + slot] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < L::NI; ++i) {
+    const int w = rloc + L::RP * i, t = t0 - HALO + w;
+    if (w < TR + HALO) {
+      float4 v = own[i];
+      if (t >= 0 && w < rows + HALO) {
+        float ss = part[w * 4];
+#pragma unroll
+        for (int sl = 1; sl < L::WPR; ++sl) ss += part[w * 4 + sl];
+        const float rstd = rsqrtf(ss / (float)C + eps);
+        v.x *= rstd * nw.x; v.y *= rstd * nw.y; v.z *= rstd * nw.z; v.w *= rstd * nw.w;
+      }
+      *reinterpret_cast<float4*>(xn + w * C + c0) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. mixer, then the FFN's RMS statistic ------------------------------------------------------------------------------------
+  float4 y1[L::NI];
+#pragma unroll
+  for (int i = 0; i < L::NI; ++i) {
+    const int w = rloc + L::RP * i, tt = w - HALO;
+    y1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tt >= 0 && tt < rows) {
+      float4 s = db;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(xn + (tt + k) * C + c0);
+        s.x = fmaf(tap[k], v.x, s.x); s.y = fmaf(tap[7 + k], v.y, s.y); s.z = fmaf(tap[14 + k], v.z, s.z); s.w = fmaf(tap[21 + k], v.w, s.w);
+      }
+      y1[i] = make_float4(own[i].x + gm.x * s.x, own[i].y + gm.y * s.y, own[i].z + gm.z * s.z, own[i].w + gm.w * s.w);
+    }
+    const float s2 = vv_wave_sum(sq4(y1[i]));
+    if (lane == 0 && w < TR + HALO) part2[w * 4 + slot] = s2;
+  }
+  // the new streaming history = the last 6 rows of [old history ; normalised rows]: all inside the LAST row tile's window
+  if (hist_new && blockIdx.x == 0 && t0 + TR >= T) {
+    for (int e = tid; e < HALO * L::F4; e += 256) {
+      const int j = e / L::F4, c4 = e - j * L::F4;
+      *reinterpret_cast<float4*>(hist_new + (size_t)j * C + 4 * c4) = *reinterpret_cast<const float4*>(xn + (size_t)(T - t0 + j) * C + 4 * c4);
+    }
+  }
+  __syncthreads();
+  {
+    const int ys0 = blockIdx.x * (C / (int)gridDim.x);              // this workgroup's columns of y
+    const bool mine = c0 >= ys0 && c0 < ys0 + C / (int)gridDim.x;
+#pragma unroll
+    for (int i = 0; i < L::NI; ++i) {
+      const int w = rloc + L::RP * i, tt = w - HALO;
+      if (tt >= 0 && tt < TR) {                                      // rows past the end of the sequence: zeros
+        float ss = part2[w * 4];
+#pragma unroll
+        for (int sl = 1; sl < L::WPR; ++sl) ss += part2[w * 4 + sl];
+        const float rstd = rsqrtf(ss / (float)C + eps);
+        uint2 p;
+        p.x = pack2(y1[i].x * rstd * fw.x, y1[i].y * rstd * fw.y);
+        p.y = pack2(y1[i].z * rstd * fw.z, y1[i].w * rstd * fw.w);
+        *reinterpret_cast<uint2*>(xh + tt * L::P1 + c0) = p;
+        if (mine && tt < rows) *reinterpret_cast<float4*>(y + (int64_t)(t0 + tt) * C + c0) = y1[i];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. hidden tile = gelu(W1 xh + b1): 32 channels x 32 rows, K split over the waves -------------------------------------------
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  {
+    const bf16_t* xf = xh + lm * L::P1 + wave * (C / 4) + hk;
+#pragma unroll
+    for (int s = 0; s < L::ST; ++s) {
+      const u32x4 xb = *reinterpret_cast<const u32x4*>(xf + s * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];      // xn is dead: every read of it sits before the last barrier
+  __syncthreads();
+  {
+    const int m = lane & 31;
+    if (m < rows) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 16 + 4 * eg + i) * 64 + lane];   // fixed order: deterministic
+        v[i] = s;
+      }
+      uint2 p;
+      p.x = pack2(vv_gelu_as(v[0] + b1v.x), vv_gelu_as(v[1] + b1v.y));
+      p.y = pack2(vv_gelu_as(v[2] + b1v.z), vv_gelu_as(v[3] + b1v.w));
+      *reinterpret_cast<uint2*>(hidden + (int64_t)(t0 + m) * (4 * C) + n0 + 8 * eg + 4 * (lane >> 5)) = p;
+    }
+  }
+}
+
+// out[T, C] = res + ffn_gamma * (W2 hidden + b2), hidden bf16 [T, 4C]
+template <int C>
+__global__ __launch_bounds__(256) void ffn_out_kernel(const bf16_t* __restrict__ hidden, const float* res, float* out, const float* __restrict__ hist_new,
+                                                      int T, const vv_block B) {
+  constexpr int K = 4 * C, ST = C / 32;                            // a wave's K quarter = C columns = C / 32 steps of 32
+  __shared__ float red[4 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16, t0 = blockIdx.y * TR2;
+  const int r16 = lane & 15, kq = lane >> 4;
+  u32x4 wf[ST], hf[ST];
+  {
+    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w2) + (int64_t)(n0 + r16) * K + wave * C + 8 * kq;
+    const bf16_t* hr = hidden + (int64_t)min(t0 + r16, T - 1) * K + wave * C + 8 * kq;
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 32);
+      hf[s] = *reinterpret_cast<const u32x4*>(hr + s * 32);
+    }
+  }
+  // epilogue operands of this thread: accumulator register ei of lane el -> channel n0 + 4 (el >> 4) + ei, row t0 + (el & 15)
+  const int ei = tid >> 6, el = tid & 63;
+  const int en = n0 + 4 * (el >> 4) + ei, em = t0 + (el & 15);
+  const bool ev = em < T;
+  const float b2v = B.b2[en], fgv = B.ffn_gamma[en];
+  const float rv = ev ? res[(int64_t)em * C + en] : 0.f;
+  // the streaming history the first kernel left in scratch moves into place (nobody reads B.hist any more in this block)
+  const bool mover = hist_new && B.hist && blockIdx.x == 0 && blockIdx.y == 0;
+  constexpr int HN = (HALO * C / 4 + 255) / 256;
+  float4 hv[HN];
+  if (mover) {
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+      const int e = tid + 256 * i;
+      hv[i] = e < HALO * C / 4 ? *reinterpret_cast<const float4*>(hist_new + 4 * (size_t)e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < ST; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, hf[s]), acc, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[(wave * 4 + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  if (ev) {
+    float s = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 4 + ei) * 64 + el];          // fixed order: deterministic
+    out[(int64_t)em * C + en] = rv + fgv * (s + b2v);
+  }
+  if (mover) {
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+      const int e = tid + 256 * i;
+      if (e < HALO * C / 4) *reinterpret_cast<float4*>(B.hist + 4 * (size_t)e) = hv[i];
+    }
+  }
+}
+
+int g_on = 1;
+
+template <int C>
+int launch_c(const vv_block& B, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, float eps, hipStream_t s) {
+  float* hn = B.hist ? hist_new : nullptr;
+  hipLaunchKernelGGL((ffn_in_kernel<C>), dim3(4 * C / 32, (T + TR - 1) / TR), dim3(256), InLay<C>::LDS, s, x, y, reinterpret_cast<bf16_t*>(hidden), hn, T, B,
+                     eps);
+  hipLaunchKernelGGL((ffn_out_kernel<C>), dim3(C / 16, (T + TR2 - 1) / TR2), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(hidden), y, out, hn, T, B);
+  return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
+}
+
+}  // namespace
+
+void vv_convffn_set(int on) { g_on = on; }
+
+int vv_convffn_init() {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)InLay<256>::LDS) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)InLay<512>::LDS) != hipSuccess)
+    return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit");
+  return 0;
+}
+
+// One Block1D of a middle stage: x[T, C] -> y[T, C] (mixer output, also the FFN residual) -> hidden (bf16 [T, 4C]) -> out[T, C]
+// (out may be y).  hist_new: 6 * C floats of scratch.  1 = enqueued, 0 = not covered (caller runs mixer + two linears), < 0 = error
+int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, int C, float eps,
+                      hipStream_t s) {
+  if (!g_on || wdt != VV_BF16 || T < 3 || T > 256 || (C != 256 && C != 512)) return 0;
+  auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
+  if (!a16(B.w1) || !a16(B.w2) || !a16(B.b1) || !B.b2 || !a16(B.gamma) || !B.ffn_gamma || !a16(B.norm_w) || !a16(B.ffn_norm_w) || !a16(B.dw_b) ||
+      !a16(B.dw_w) || !a16(x) || !a16(y) || !a16(hidden) || !a16(hist_new) || !out || (B.hist && !a16(B.hist)))
+    return 0;
+  {   // workgroups read x (and halo rows) while others already write y / hidden: the ranges must be disjoint
+    const uintptr_t xa = (uintptr_t)x, ya = (uintptr_t)y, bytes = (uintptr_t)T * C * 4;
+    if (xa < ya + bytes && ya < xa + bytes) return 0;
+  }
+  if (C == 256) return launch_c<256>(B, x, y, hidden, hist_new, out, T, eps, s);
+  return launch_c<512>(B, x, y, hidden, hist_new, out, T, eps, s);
+}
+
+extern "C" size_t vv_block_mid_ws_bytes(int T, int C) { return (size_t)T * C * 4 + (size_t)T * 4 * C * 2 + (size_t)HALO * C * 4 + 64; }
+
+extern "C" int vv_block_mid(const vv_block* b, int wdt, const float* x, float* out, void* ws, int T, int C, float eps, vv_stream_t stream) {
+  if (!b || !x || !out || !ws || T <= 0) return vv_set_error(VV_E_ARG, "vv_block_mid: bad args");
+  float* y = reinterpret_cast<float*>(ws);
+  char* hidden = reinterpret_cast<char*>(ws) + (size_t)T * C * 4;
+  float* hn = reinterpret_cast<float*>(hidden + (size_t)T * 4 * C * 2);
+  const int rc = vv_launch_convffn(*b, wdt, x, y, hidden, hn, out, T, C, eps, (hipStream_t)stream);
+  if (rc < 0) return rc;
+  if (rc == 0) return vv_set_error(VV_E_UNSUPPORTED, "vv_block_mid: shape not covered (C=%d T=%d wdt=%d)", C, T, wdt);
+  return 0;
+}

@@ -35,6 +35,7 @@ extern "C" int vv_init(void) {
   VV_TRY(vv_mixer_init());
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
+  VV_TRY(vv_convffn_init());
   return vv_chain_init();
 }
 void vv_gemv_stream_set_blocks(int b);
@@ -61,6 +62,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
   if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
+  if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
   if (key && !strcmp(key, "chain_blocks")) { vv_chain_set_blocks(value); return 0; }
   if (key && !strcmp(key, "chain_dbg_mode")) { vv_chain_set_dbg_mode(value); return 0; }
   if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }

@@ -381,6 +381,18 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     }
     float* final_dst = last ? (next_pad ? next_pad : cur) + (size_t)nctx * C : nullptr;
     if (last) *pad_out = next_pad ? next_pad : cur;
+    {   // middle stages of a streaming frame (C = 256 / 512): mixer + first GEMM, second GEMM (vv_convffn.hip); the bf16 hidden tile
+        // fills the first half of `hid`, the scratch history sits behind it
+      float* dst2 = (last && final_dst) ? final_dst : other;
+      const int two = vv_launch_convffn(B, net->wdt, cur, other, hid, reinterpret_cast<float*>(reinterpret_cast<char*>(hid) + (size_t)T * 4 * C * 2),
+                                        dst2, (int)T, C, net->eps, (hipStream_t)stream);
+      if (two < 0) return two;
+      if (two) {
+        if (dst2 == other) { float* t = cur; cur = other; other = t; }
+        else { cur = nullptr; }
+        continue;
+      }
+    }
     VV_TRY(vv_block_mixer(cur, other, (int)T, C, B.norm_w, net->eps, B.dw_w, B.dw_b, B.gamma, B.hist, stream));
     // T > 8 rows on bf16 weights: both FFN linears run on the matrix cores and the 4C-wide hidden activation is handed
     // over in bf16 (half the bytes, and the second GEMM reads its fragments straight from it: no LDS staging)
