@@ -251,7 +251,31 @@ def test_block1d_single_launch_vs_torch(lib, C_, T):
     assert l.vv_block1d(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), 8, C_, eps, None) != 0
 
 
-@pytest.mark.parametrize("C_,T", [(512, 40), (256, 200), (512, 37), (256, 5), (512, 64), (256, 256), (512, 3)])
+@pytest.mark.parametrize("m,n,k,ldx", [(40, 512, 2560, 1280), (200, 256, 1024, 512), (40, 1280, 1024, 1024), (200, 512, 512, 512), (8, 2560, 2048, 2048),
+                                       (37, 48, 2560, 2564), (5, 16, 512, 512), (256, 1024, 1024, 1028)])
+def test_resampling_conv_skinny_gemm_vs_torch(lib, m, n, k, ldx):
+    """vv_linear at the shapes of a streaming frame's resampling convs (fp32 rows with overlapping windows: ldx < k for a strided conv,
+    bf16 weights, bias, no activation): the LDS-free skinny kernel of vv_convffn.hip against torch on the bf16-rounded operands."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(m + n + k)
+    buf = torch.randn((m - 1) * ldx + k, generator=g)
+    x = torch.stack([buf[i * ldx: i * ldx + k] for i in range(m)])
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    bias = torch.randn(n, generator=g) * 0.1
+    bd, wd, xd = bias.cuda(), w.cuda(), buf.cuda()
+    out = torch.full((m, n), float("nan"), device="cuda")
+    a = L.LinArgs()
+    a.x, a.ldx, a.m, a.n, a.k, a.wdt, a.out, a.ldo = xd.data_ptr(), ldx, m, n, k, L.VV_BF16, out.data_ptr(), n
+    a.w, a.bias = wd.data_ptr(), bd.data_ptr()
+    L.check(l.vv_linear(C.byref(a), None), "vv_linear")
+    torch.cuda.synchronize()
+    want = x.bfloat16().float() @ w.float().T + bias
+    e = rel_rms(out.cpu().numpy(), want.numpy())
+    assert e < 1e-5, f"m={m} n={n} k={k} ldx={ldx}: rel RMS {e:.3e}"
+
+
+@pytest.mark.parametrize("C_,T", [(512, 40), (256, 200), (512, 37), (256, 5), (512, 64), (256, 256), (512, 3), (1024, 8), (1024, 13), (1024, 4)])
 def test_block_mid_two_launches_vs_torch(lib, C_, T):
     """vv_block_mid (middle-stage Block1D of a streaming frame as two launches: mixer + first FFN GEMM, second FFN GEMM; vv_convffn.hip)
     against the torch fp32 restatement of Block1D.forward (modular_vibevoice_tokenizer.py:555-600) on the same bf16-rounded weights:

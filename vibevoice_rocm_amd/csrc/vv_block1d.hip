@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   const int c0 = cq * 4;
 
   // The weights do not depend on the activations: this wave's W1 fragments (C/32 blocks x C/16 steps x 16 B per lane, <= 128
-  // VGPRs) are requested before anything else so their L2 latency hides behind the mixer; W2 follows in double-buffered batches.
+  // VGPRs) are requested before anything else so their L2 latency hides behind the mixer.
   const int hk = (lane >> 5) * 8;                                  // k offset of this lane inside a 16-wide MFMA step
   const int lm = lane & 31;
   constexpr int NBW = C / 32;                                      // W1 output blocks per wave
@@ -94,10 +94,37 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     }
   }
 
+  // second GEMM: C/32 output blocks, K = 4C split over 4 / (C/32) waves.  All of this wave's W2 fragments (<= 128 VGPRs) and every
+  // per-channel parameter of the kernel are requested here too: nothing but the window load below sits on the critical path, the
+  // later phases find their operands in registers instead of starting another trip to L2 each.
+  constexpr int ST2 = (4 * C / 16) / L::KS;                        // MFMA steps of this wave in the second GEMM
+  const int nblk = wave % L::NB2, kpart = wave / L::NB2;
+  u32x4 w2f[ST2];
+  {
+    const bf16_t* w2r = reinterpret_cast<const bf16_t*>(B.w2) + (int64_t)(nblk * 32 + lm) * (4 * C) + kpart * ST2 * 16 + hk;
+#pragma unroll
+    for (int i = 0; i < ST2; ++i) w2f[i] = *reinterpret_cast<const u32x4*>(w2r + i * 16);
+  }
+
   // ---- 1. window rows t0-6 .. t0+rows-1: raw values stay in registers, normalised values go to LDS -----------------------
   float4 own[L::NI];
   float ss[L::NI];
   const float4 nw = *reinterpret_cast<const float4*>(B.norm_w + c0);
+  float tap[4][7];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tap[c][k] = B.dw_w[(c0 + c) * 7 + k];
+  const float4 db = *reinterpret_cast<const float4*>(B.dw_b + c0);
+  const float4 gm = *reinterpret_cast<const float4*>(B.gamma + c0);
+  const float4 fw = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0);
+  float4 b2v[4], fgv[4];                                           // epilogue of the second GEMM (channel runs of this lane)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int n = nblk * 32 + 8 * g + 4 * (lane >> 5);
+    b2v[g] = *reinterpret_cast<const float4*>(B.b2 + n);
+    fgv[g] = *reinterpret_cast<const float4*>(B.ffn_gamma + n);
+  }
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i, t = t0 - HALO + w;
@@ -125,15 +152,13 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   __syncthreads();
 
   // ---- 2. mixer + FFN RMSNorm: x1 = x + gamma (dwconv7(xn) + b); xh = bf16(x1 rstd ffn_norm_w) ----------------------------
+  // first GEMM's bias runs: requested now, they arrive while the mixer computes
+  float4 b1v[NBW][4];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b1v[j][g] = *reinterpret_cast<const float4*>(B.b1 + (wave * NBW + j) * 32 + 8 * g + 4 * (lane >> 5));
   {
-    float tap[4][7];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int k = 0; k < 7; ++k) tap[c][k] = B.dw_w[(c0 + c) * 7 + k];
-    const float4 db = *reinterpret_cast<const float4*>(B.dw_b + c0);
-    const float4 gm = *reinterpret_cast<const float4*>(B.gamma + c0);
-    const float4 fw = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0);
     float4 x1[L::NI];
     float s2[L::NI];
 #pragma unroll
@@ -169,15 +194,6 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   __syncthreads();
 
   // ---- 3. hidden = gelu(W1 xh + b1): 4C/32 output blocks, C/32 per wave; K = C ----------------------------------------------
-  // second GEMM: C/32 output blocks, K = 4C split over 4 / (C/32) waves; its first weight batch is requested here, before the
-  // first GEMM's epilogue and the barrier
-  constexpr int ST2 = (4 * C / 16) / L::KS;                        // MFMA steps of this wave in the second GEMM
-  constexpr int UB = ST2 < 8 ? ST2 : 8;
-  const int nblk = wave % L::NB2, kpart = wave / L::NB2;
-  const bf16_t* w2r = reinterpret_cast<const bf16_t*>(B.w2) + (int64_t)(nblk * 32 + lm) * (4 * C) + kpart * ST2 * 16 + hk;
-  u32x4 w2a[UB], w2b[UB];
-#pragma unroll
-  for (int i = 0; i < UB; ++i) w2a[i] = *reinterpret_cast<const u32x4*>(w2r + i * 16);
   {
     const bf16_t* xf = xh + lm * L::P1 + hk;
 #pragma unroll
@@ -194,7 +210,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {                              // acc[4g + i]: channel n0 + 8g + 4(lane >> 5) + i, row lane & 31
         const int n = n0 + 8 * g + 4 * (lane >> 5);
-        const float4 b1 = *reinterpret_cast<const float4*>(B.b1 + n);
+        const float4 b1 = b1v[j][g];
         uint2 p;
         p.x = pack2(gelu1(acc[4 * g] + b1.x), gelu1(acc[4 * g + 1] + b1.y));
         p.y = pack2(gelu1(acc[4 * g + 2] + b1.z), gelu1(acc[4 * g + 3] + b1.w));
@@ -210,27 +226,10 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    auto mma = [&](const u32x4 (&w)[UB], int sb) {
 #pragma unroll
-      for (int i = 0; i < UB; ++i) {
-        const u32x4 hb = *reinterpret_cast<const u32x4*>(hf + (sb + i) * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, hb), acc, 0, 0, 0);
-      }
-    };
-#pragma unroll
-    for (int sb = 0; sb < ST2; sb += 2 * UB) {                     // batches alternate between two register sets: no rotation
-      if (sb + UB < ST2) {
-#pragma unroll
-        for (int i = 0; i < UB; ++i) w2b[i] = *reinterpret_cast<const u32x4*>(w2r + (sb + UB + i) * 16);
-      }
-      mma(w2a, sb);
-      if (sb + UB < ST2) {
-        if (sb + 2 * UB < ST2) {
-#pragma unroll
-          for (int i = 0; i < UB; ++i) w2a[i] = *reinterpret_cast<const u32x4*>(w2r + (sb + 2 * UB + i) * 16);
-        }
-        mma(w2b, sb + UB);
-      }
+    for (int i = 0; i < ST2; ++i) {
+      const u32x4 hb = *reinterpret_cast<const u32x4*>(hf + i * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w2f[i]), __builtin_bit_cast(bf16x8, hb), acc, 0, 0, 0);
     }
     if (L::KS > 1) {                                               // fixed-order combine: deterministic
       if (kpart > 0) {
@@ -249,8 +248,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = nblk * 32 + 8 * g + 4 * (lane >> 5);
-        const float4 b2 = *reinterpret_cast<const float4*>(B.b2 + n);
-        const float4 fg = *reinterpret_cast<const float4*>(B.ffn_gamma + n);
+        const float4 b2 = b2v[g], fg = fgv[g];
         const float4 r1 = *reinterpret_cast<const float4*>(x1s + lm * C + n);
         float4 o;
         o.x = r1.x + fg.x * (acc[4 * g] + b2.x);

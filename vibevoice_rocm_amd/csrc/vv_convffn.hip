@@ -32,7 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TR = 32;          // rows per workgroup of ffn_in (one 32 x 32 MFMA tile)
 constexpr int TR2 = 16;         // rows per workgroup of ffn_out (one 16 x 16 MFMA tile)
 constexpr int HALO = 6;         // causal depthwise kernel 7
 
@@ -42,24 +41,25 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 }
 __device__ __forceinline__ float sq4(const float4 v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 
-template <int C> struct InLay {
+template <int C, int TRV> struct InLay {                  // TRV: sequence rows per workgroup (<= 32; the MFMA tile stays 32 wide)
   static constexpr int F4 = C / 4;                        // float4 columns per row = threads per row
   static constexpr int RP = 256 / F4;                     // window rows per pass of the 256 threads
-  static constexpr int NI = (TR + HALO + RP - 1) / RP;    // passes over the 38-row window
+  static constexpr int NI = (TRV + HALO + RP - 1) / RP;   // passes over the window (TRV + 6 rows)
   static constexpr int WPR = F4 / 64;                     // waves per row (partial sums of squares per row)
   static constexpr int P1 = C + 8;                        // bf16 pitch of the FFN input image
   static constexpr int ST = C / 64;                       // MFMA steps of one wave (K split over the 4 waves)
-  static constexpr size_t XN = (size_t)(TR + HALO) * C * 4;
+  static constexpr size_t XN = (size_t)(TRV + HALO) * C * 4;
   static constexpr size_t RED = (size_t)4 * 16 * 64 * 4;  // K-split partial accumulators (alias the window once it is consumed)
-  static constexpr size_t XH = (size_t)TR * P1 * 2;
-  static constexpr size_t PART = (size_t)2 * (TR + HALO) * 4 * 4;
+  static constexpr size_t XH = (size_t)TRV * P1 * 2;
+  static constexpr size_t PART = (size_t)2 * (TRV + HALO) * 4 * 4;
   static constexpr size_t LDS = (XN > RED ? XN : RED) + XH + PART;
 };
 
-template <int C>
+template <int C, int TRV>
 __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ hidden,
                                                      float* __restrict__ hist_new, int T, const vv_block B, float eps) {
-  using L = InLay<C>;
+  using L = InLay<C, TRV>;
+  constexpr int TR = TRV;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xn = reinterpret_cast<float*>(smem);                                        // [TR + 6][C] normalised window
   float* red = reinterpret_cast<float*>(smem);                                       // aliases xn after the conv
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   {
-    const bf16_t* xf = xh + lm * L::P1 + wave * (C / 4) + hk;
+    const bf16_t* xf = xh + min(lm, TR - 1) * L::P1 + wave * (C / 4) + hk;     // tile columns past TR repeat a row (never stored)
 #pragma unroll
     for (int s = 0; s < L::ST; ++s) {
       const u32x4 xb = *reinterpret_cast<const u32x4*>(xf + s * 16);
@@ -211,18 +211,18 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 }
 
 // out[T, C] = res + ffn_gamma * (W2 hidden + b2), hidden bf16 [T, 4C]
-template <int C>
-__global__ __launch_bounds__(256) void ffn_out_kernel(const bf16_t* __restrict__ hidden, const float* res, float* out, const float* __restrict__ hist_new,
-                                                      int T, const vv_block B) {
-  constexpr int K = 4 * C, ST = C / 32;                            // a wave's K quarter = C columns = C / 32 steps of 32
-  __shared__ float red[4 * 4 * 64];
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) void ffn_out_kernel(const bf16_t* __restrict__ hidden, const float* res, float* out, const float* __restrict__ hist_new,
+                                                          int T, const vv_block B) {
+  constexpr int K = 4 * C, KW = K / NW, ST = KW / 32;              // a wave's share of K = KW columns = ST steps of 32
+  __shared__ float red[NW * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16, t0 = blockIdx.y * TR2;
   const int r16 = lane & 15, kq = lane >> 4;
   u32x4 wf[ST], hf[ST];
   {
-    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w2) + (int64_t)(n0 + r16) * K + wave * C + 8 * kq;
-    const bf16_t* hr = hidden + (int64_t)min(t0 + r16, T - 1) * K + wave * C + 8 * kq;
+    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w2) + (int64_t)(n0 + r16) * K + wave * KW + 8 * kq;
+    const bf16_t* hr = hidden + (int64_t)min(t0 + r16, T - 1) * K + wave * KW + 8 * kq;
 #pragma unroll
     for (int s = 0; s < ST; ++s) {
       wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 32);
@@ -230,19 +230,19 @@ __global__ __launch_bounds__(256) void ffn_out_kernel(const bf16_t* __restrict__
     }
   }
   // epilogue operands of this thread: accumulator register ei of lane el -> channel n0 + 4 (el >> 4) + ei, row t0 + (el & 15)
-  const int ei = tid >> 6, el = tid & 63;
+  const int ei = (tid >> 6) & 3, el = tid & 63;
   const int en = n0 + 4 * (el >> 4) + ei, em = t0 + (el & 15);
-  const bool ev = em < T;
+  const bool ev = em < T && tid < 256;
   const float b2v = B.b2[en], fgv = B.ffn_gamma[en];
   const float rv = ev ? res[(int64_t)em * C + en] : 0.f;
   // the streaming history the first kernel left in scratch moves into place (nobody reads B.hist any more in this block)
   const bool mover = hist_new && B.hist && blockIdx.x == 0 && blockIdx.y == 0;
-  constexpr int HN = (HALO * C / 4 + 255) / 256;
+  constexpr int HN = (HALO * C / 4 + 64 * NW - 1) / (64 * NW);
   float4 hv[HN];
   if (mover) {
 #pragma unroll
     for (int i = 0; i < HN; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + 64 * NW * i;
       hv[i] = e < HALO * C / 4 ? *reinterpret_cast<const float4*>(hist_new + 4 * (size_t)e) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
@@ -256,36 +256,104 @@ __global__ __launch_bounds__(256) void ffn_out_kernel(const bf16_t* __restrict__
   if (ev) {
     float s = 0.f;
 #pragma unroll
-    for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 4 + ei) * 64 + el];          // fixed order: deterministic
+    for (int w4 = 0; w4 < NW; ++w4) s += red[(w4 * 4 + ei) * 64 + el];         // fixed order: deterministic
     out[(int64_t)em * C + en] = rv + fgv * (s + b2v);
   }
   if (mover) {
 #pragma unroll
     for (int i = 0; i < HN; ++i) {
-      const int e = tid + 256 * i;
+      const int e = tid + 64 * NW * i;
       if (e < HALO * C / 4) *reinterpret_cast<float4*>(B.hist + 4 * (size_t)e) = hv[i];
     }
   }
 }
 
+// ---- resampling convs of a streaming frame as skinny GEMMs ------------------------------------------------------------------------------
+// out[M, N] = x[M, K] W[N, K]^T + bias: fp32 rows (pitch ldx: the overlapping windows of a strided conv's padded input), bf16 weights,
+// M <= a few hundred rows, K = 512 .. 2560.  The general kernels stage x through LDS in K chunks with a barrier pair per chunk
+// (43 us for the 256 -> 512 stride-5 conv: 32 workgroups walking K = 2560).  Here a workgroup owns 16 rows x 16 channels on
+// mfma_f32_16x16x32_bf16, K split over its 4 waves; a lane's B fragment is 8 consecutive floats of its row, converted in registers -
+// no LDS image, no barrier before the MFMAs, every load of the kernel requested up front.
+template <int NST>
+__global__ __launch_bounds__(256) void skinny_kernel(const float* __restrict__ x, int64_t ldx, int M, const bf16_t* __restrict__ W, int K,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int64_t ldo) {
+  __shared__ float red[4 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16, t0 = blockIdx.y * 16;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int kb = wave * (32 * NST) + 8 * kq;
+  const bf16_t* wr = W + (int64_t)(n0 + r16) * K + kb;
+  const float* xr = x + (int64_t)min(t0 + r16, M - 1) * ldx + kb;
+  u32x4 wf[NST];
+  float4 xa[NST], xb[NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    wf[s] = *reinterpret_cast<const u32x4*>(wr + 32 * s);
+    xa[s] = *reinterpret_cast<const float4*>(xr + 32 * s);
+    xb[s] = *reinterpret_cast<const float4*>(xr + 32 * s + 4);
+  }
+  const int ei = tid >> 6, el = tid & 63;
+  const int en = n0 + 4 * (el >> 4) + ei, em = t0 + (el & 15);
+  const float bv = bias ? bias[en] : 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    u32x4 p;
+    p.x = pack2(xa[s].x, xa[s].y); p.y = pack2(xa[s].z, xa[s].w); p.z = pack2(xb[s].x, xb[s].y); p.w = pack2(xb[s].z, xb[s].w);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[(wave * 4 + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  if (em < M) {
+    float v = 0.f;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * 4 + ei) * 64 + el];           // fixed order: deterministic
+    out[(int64_t)em * ldo + en] = v + bv;
+  }
+}
+
+int g_skinny = 1, g_skinny_min_m = 5, g_skinny_max_m = 256;
+
 int g_on = 1;
 
-template <int C>
+template <int C, int TRV, int NW>
 int launch_c(const vv_block& B, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, float eps, hipStream_t s) {
   float* hn = B.hist ? hist_new : nullptr;
-  hipLaunchKernelGGL((ffn_in_kernel<C>), dim3(4 * C / 32, (T + TR - 1) / TR), dim3(256), InLay<C>::LDS, s, x, y, reinterpret_cast<bf16_t*>(hidden), hn, T, B,
-                     eps);
-  hipLaunchKernelGGL((ffn_out_kernel<C>), dim3(C / 16, (T + TR2 - 1) / TR2), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(hidden), y, out, hn, T, B);
+  constexpr size_t lds = InLay<C, TRV>::LDS;
+  hipLaunchKernelGGL((ffn_in_kernel<C, TRV>), dim3(4 * C / 32, (T + TRV - 1) / TRV), dim3(256), lds, s, x, y, reinterpret_cast<bf16_t*>(hidden), hn, T, B, eps);
+  hipLaunchKernelGGL((ffn_out_kernel<C, NW>), dim3(C / 16, (T + TR2 - 1) / TR2), dim3(64 * NW), 0, s, reinterpret_cast<const bf16_t*>(hidden), y, out, hn, T, B);
   return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
 }
 
 }  // namespace
 
 void vv_convffn_set(int on) { g_on = on; }
+void vv_skinny_set(int on, int min_m, int max_m) { g_skinny = on; if (min_m > 0) g_skinny_min_m = min_m; if (max_m > 0) g_skinny_max_m = max_m; }
+
+// 1 = launched, 0 = not covered
+int vv_launch_skinny(const vv_lin_args& a, hipStream_t s) {
+  if (!g_skinny || a.wdt != VV_BF16 || a.w2 || a.pro != VV_PRO_NONE || a.act != VV_ACT_NONE || a.gate || a.res || a.mod_scale || a.flags) return 0;
+  if (a.m < g_skinny_min_m || a.m > g_skinny_max_m || a.n % 16 || a.ldx % 4 || a.ldx == 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 0;
+  dim3 grid(a.n / 16, (a.m + 15) / 16);
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(a.w);
+#define VV_SK(NSTV) hipLaunchKernelGGL((skinny_kernel<NSTV>), grid, dim3(256), 0, s, a.x, a.ldx, a.m, W, a.k, a.bias, a.out, a.ldo)
+  switch (a.k) {
+    case 512: VV_SK(4); break;
+    case 1024: VV_SK(8); break;
+    case 2048: VV_SK(16); break;
+    case 2560: VV_SK(20); break;
+    default: return 0;
+  }
+#undef VV_SK
+  return 1;
+}
 
 int vv_convffn_init() {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)InLay<256>::LDS) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)InLay<512>::LDS) != hipSuccess)
+  constexpr int l256 = (int)InLay<256, 32>::LDS, l512 = (int)InLay<512, 32>::LDS, l1024 = (int)InLay<1024, 8>::LDS;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<256, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, l256) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<512, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, l512) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, l1024) != hipSuccess)
     return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit");
   return 0;
 }
@@ -294,7 +362,7 @@ int vv_convffn_init() {
 // (out may be y).  hist_new: 6 * C floats of scratch.  1 = enqueued, 0 = not covered (caller runs mixer + two linears), < 0 = error
 int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, int C, float eps,
                       hipStream_t s) {
-  if (!g_on || wdt != VV_BF16 || T < 3 || T > 256 || (C != 256 && C != 512)) return 0;
+  if (!g_on || wdt != VV_BF16 || T < 3 || T > 256 || (C != 256 && C != 512 && C != 1024) || (C == 1024 && T > 64)) return 0;
   auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
   if (!a16(B.w1) || !a16(B.w2) || !a16(B.b1) || !B.b2 || !a16(B.gamma) || !B.ffn_gamma || !a16(B.norm_w) || !a16(B.ffn_norm_w) || !a16(B.dw_b) ||
       !a16(B.dw_w) || !a16(x) || !a16(y) || !a16(hidden) || !a16(hist_new) || !out || (B.hist && !a16(B.hist)))
@@ -303,8 +371,9 @@ int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void
     const uintptr_t xa = (uintptr_t)x, ya = (uintptr_t)y, bytes = (uintptr_t)T * C * 4;
     if (xa < ya + bytes && ya < xa + bytes) return 0;
   }
-  if (C == 256) return launch_c<256>(B, x, y, hidden, hist_new, out, T, eps, s);
-  return launch_c<512>(B, x, y, hidden, hist_new, out, T, eps, s);
+  if (C == 256) return launch_c<256, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+  if (C == 512) return launch_c<512, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+  return launch_c<1024, 8, 8>(B, x, y, hidden, hist_new, out, T, eps, s);     // T = 8 rows per frame: 8-row tiles, K = 4096 over 8 waves
 }
 
 extern "C" size_t vv_block_mid_ws_bytes(int T, int C) { return (size_t)T * C * 4 + (size_t)T * 4 * C * 2 + (size_t)HALO * C * 4 + 64; }

@@ -63,6 +63,9 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
+  if (key && !strcmp(key, "skinny")) { vv_skinny_set(value, 0, 0); return 0; }
+  if (key && !strcmp(key, "skinny_min_m")) { vv_skinny_set(1, value, 0); return 0; }
+  if (key && !strcmp(key, "skinny_max_m")) { vv_skinny_set(1, 0, value); return 0; }
   if (key && !strcmp(key, "chain_blocks")) { vv_chain_set_blocks(value); return 0; }
   if (key && !strcmp(key, "chain_dbg_mode")) { vv_chain_set_dbg_mode(value); return 0; }
   if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }
@@ -499,6 +502,7 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const bool dual = a.w2 != nullptr;
   const size_t wsz = sizeof(WT);
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
+  if (vv_launch_skinny(a, s)) return 0;                          // a few rows x K = 512..2560, plain epilogue: the resampling convs (vv_convffn.hip)
   if (a.m <= 8) {
     if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
