@@ -46,7 +46,7 @@ def short(name):
 
 
 def split_frames(rows):
-    cuts = [i for i, r in enumerate(rows) if "advance_lens" in r["Kernel_Name"] or "llm_tail_kernel" in r["Kernel_Name"]]
+    cuts = [i for i, r in enumerate(rows) if "advance_lens" in r["Kernel_Name"] or "llm_tail" in r["Kernel_Name"]]
     frames = [rows[cuts[i] + 1: cuts[i + 1] + 1] for i in range(len(cuts) - 1)]
     lens = collections.Counter(len(f) for f in frames)
     n_typ = lens.most_common(1)[0][0]

@@ -57,6 +57,8 @@ int vv_head_init_fused(const vv_head* h, const float* noise, float* Xs, float* M
 bool vv_head_boundary_supported(const vv_head* h);
 int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
                            const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s);
+int vv_fused_init();
+int vv_head_modulations_fused(const vv_head* h, const void* c_bf16, int rows, float* const* mod, float* modf, hipStream_t s);   // 1 launched, 0 not covered
 struct vv_conv_ctx_item { float* pad; float* state; int ctx, T, C; };
 int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStream_t s);   // scatter 0: pad[0:ctx] <- state; 1: state <- pad[T : T + ctx]
 int vv_block1d_init();                                            // vv_block1d.hip

@@ -233,6 +233,98 @@ __global__ __launch_bounds__(256) void llm_tail_kernel(const float* h, int64_t l
   }
 }
 
+// The decode shape (R <= 2 rows, <= 8 constrained ids, H <= 4096): every operand - the rows, the norm weight, this thread's 4-column
+// slices of the constrained vocabulary rows, ids, forced token - is requested in one burst, then two barriers: row statistics,
+// logit partials.  The general kernel above walks rows and vocabulary rows one after the other (5-6 dependent trips, 21 us).
+template <typename WT>
+__global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int64_t ldh, int R, int H, const float* norm_w, float eps, float* out, int64_t ldo,
+                                                            const WT* w_valid, int nv, const int* ids, float* logits_out, int* token_out, const int* forced,
+                                                            int* lens, int tok_start, int tok_diff, int* frame_ctr) {
+  constexpr int NC = 4, NV = 8;                    // column chunks (of 4) per thread per row, constrained ids
+  __shared__ float red[4][2];
+  __shared__ float lgp[4][NV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H4 = H >> 2;
+  float4 xv[2][NC], nw[NC], wv[NV][NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int ch = tid + 256 * c;
+    const int k = ch < H4 ? 4 * ch : 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) xv[r][c] = *reinterpret_cast<const float4*>(h + (int64_t)(r < R ? r : 0) * ldh + k);
+    nw[c] = *reinterpret_cast<const float4*>(norm_w + k);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const WT* wr = w_valid + (int64_t)(i < nv ? i : 0) * H + k;
+      if constexpr (sizeof(WT) == 2) {
+        const uint2 p = *reinterpret_cast<const uint2*>(wr);
+        wv[i][c] = make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u));
+      } else {
+        wv[i][c] = *reinterpret_cast<const float4*>(wr);
+      }
+    }
+  }
+  int idv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) idv[i] = ids[i < nv ? i : 0];
+  const int fv = forced ? *forced : -1;
+  const int l0 = lens ? lens[0] : 0, l1 = lens ? lens[1] : 0, fc = frame_ctr ? *frame_ctr : 0;
+  float ss[2] = {0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const bool cv = tid + 256 * c < H4;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float4 v = xv[r][c];
+      ss[r] += cv ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+    }
+  }
+  ss[0] = vv_wave_sum(ss[0]); ss[1] = vv_wave_sum(ss[1]);
+  if (lane == 0) { red[wave][0] = ss[0]; red[wave][1] = ss[1]; }
+  __syncthreads();
+  float lg[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lg[i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r >= R) break;
+    const float rstd = rsqrtf(((red[0][r] + red[1][r]) + (red[2][r] + red[3][r])) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int ch = tid + 256 * c;
+      if (ch >= H4) continue;
+      const float4 v = make_float4(xv[r][c].x * rstd * nw[c].x, xv[r][c].y * rstd * nw[c].y, xv[r][c].z * rstd * nw[c].z, xv[r][c].w * rstd * nw[c].w);
+      *reinterpret_cast<float4*>(out + (int64_t)r * ldo + 4 * ch) = v;
+      if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) lg[i] += (wv[i][c].x * v.x + wv[i][c].y * v.y) + (wv[i][c].z * v.z + wv[i][c].w * v.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float t = vv_wave_sum(lg[i]);
+    if (lane == 0) lgp[wave][i] = t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float l[NV];
+    int best = 0;
+    for (int i = 0; i < nv; ++i) {
+      l[i] = (lgp[0][i] + lgp[1][i]) + (lgp[2][i] + lgp[3][i]);
+      logits_out[i] = l[i];
+      if (i && (l[i] > l[best] || (l[i] == l[best] && idv[i] < idv[best]))) best = i;
+    }
+    const int t = fv >= 0 ? fv : idv[best];
+    *token_out = t;
+    if (lens) {
+      lens[0] = l0 + 1;
+      if (t == tok_start) lens[1] = 0;
+      else if (t == tok_diff) { lens[1] = l1 + 1; if (frame_ctr) *frame_ctr = fc + 1; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // streaming conv contexts of a whole tokenizer
 // ---------------------------------------------------------------------------------------------------------------
@@ -256,6 +348,156 @@ __global__ __launch_bounds__(256) void conv_ctx_scatter_kernel(const CtxArgs a) 
   for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += gridDim.x * 1024) {
     if (i + 3 < n && (n & 3) == 0 && (((int64_t)it.T * it.C) & 3) == 0) *reinterpret_cast<float4*>(it.state + i) = *reinterpret_cast<const float4*>(src + i);
     else for (int j = i; j < n && j < i + 4; ++j) it.state[j] = src[j];
+  }
+}
+
+
+// ---- all adaLN modulations of a frame in ONE launch ---------------------------------------------------------------------------------
+// mod[l][r, :] = adaLN_l c[r, :] for the 2 * n_steps conditioning rows c (bf16), every layer l and the final layer: 5 skinny GEMMs
+// (40 rows x 4608 / 3072 outputs, K = 1536 at 1.5B) that ran as five launches of the LDS-tiled kernel on 72 workgroups each
+// (12-15 us apiece, 65 us per frame).  Here workgroup bx owns 16 output channels of ONE of the matrices and NM row tiles of 16 rows on
+// mfma_f32_16x16x32_bf16, K split over its 4 waves; weight and activation fragments are all requested up front, no LDS image.
+struct AdaTab { const bf16_t* w[17]; float* out[17]; int nblk[17]; int ldo[17]; int n; };
+
+typedef __bf16 ad_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ad_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ad_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NST, int NM>
+__global__ __launch_bounds__(256) void adaln_all_kernel(const bf16_t* __restrict__ c, int rows, int D, const AdaTab tab) {
+  __shared__ float red[4 * NM * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx = blockIdx.x, l = 0;
+  while (l + 1 < tab.n && bx >= tab.nblk[l]) { bx -= tab.nblk[l]; ++l; }
+  const int n0 = bx * 16, m0 = blockIdx.y * (16 * NM);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int kb = wave * (32 * NST) + 8 * kq;
+  const bf16_t* wr = tab.w[l] + (int64_t)(n0 + r16) * D + kb;
+  ad_u32x4 wf[NST], xf[NM][NST];
+#pragma unroll
+  for (int s = 0; s < NST; ++s) wf[s] = *reinterpret_cast<const ad_u32x4*>(wr + 32 * s);
+#pragma unroll
+  for (int t = 0; t < NM; ++t) {
+    const bf16_t* xr = c + (int64_t)min(m0 + 16 * t + r16, rows - 1) * D + kb;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) xf[t][s] = *reinterpret_cast<const ad_u32x4*>(xr + 32 * s);
+  }
+  ad_f32x4 acc[NM];
+#pragma unroll
+  for (int t = 0; t < NM; ++t) acc[t] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NST; ++s)
+#pragma unroll
+    for (int t = 0; t < NM; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ad_bf16x8, wf[s]), __builtin_bit_cast(ad_bf16x8, xf[t][s]), acc[t], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < NM; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[((wave * NM + t) * 4 + i) * 64 + lane] = acc[t][i];
+  __syncthreads();
+  const int ei = tid >> 6, el = tid & 63;                          // accumulator register ei of lane el: channel n0 + 4 (el >> 4) + ei, row (el & 15)
+  float* out = tab.out[l];
+  const int ldo = tab.ldo[l];
+#pragma unroll
+  for (int t = 0; t < NM; ++t) {
+    const int m = m0 + 16 * t + (el & 15);
+    if (m < rows) {
+      float v = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) v += red[((w4 * NM + t) * 4 + ei) * 64 + el];      // fixed order: deterministic
+      out[(int64_t)m * ldo + n0 + 4 * (el >> 4) + ei] = v;
+    }
+  }
+}
+
+// The same with the conditioning rows resident in LDS (D = 1536: <= 48 rows x 3 KB): in the kernel above every workgroup pulls all of c
+// through L2 for 16 output channels (1344 workgroups x 147 KB = 3x the weight bytes).  Here one workgroup per CU stages its row group
+// once and walks output blocks bx, bx + grid, ...: weights stream from memory one block ahead, activation fragments come from LDS.
+template <int NST>
+__global__ __launch_bounds__(256) void adaln_lds_kernel(const bf16_t* __restrict__ c, int rows, const AdaTab tab, int total) {
+  constexpr int D = 4 * 32 * NST, P = D + 8, NM = 3, RG = 40;     // 40 rows per group (2 x 20 solver steps): 40 x 3 KB + partials fit the 160 KB LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char ad_smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(ad_smem);                                   // [nr][P]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * RG;
+  const int nr = min(RG, rows - m0);
+  float* red = reinterpret_cast<float*>(ad_smem + (size_t)RG * P * 2);              // [2][4 waves][NM][4][64]
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int kb = wave * (32 * NST) + 8 * kq;
+  auto locate = [&](int bx, int& l, int& n0) { l = 0; while (l + 1 < tab.n && bx >= tab.nblk[l]) { bx -= tab.nblk[l]; ++l; } n0 = bx * 16; };
+  ad_u32x4 wcur[NST], wnxt[NST];
+  int bx = blockIdx.x, l, n0;
+  locate(bx, l, n0);
+  {
+    const bf16_t* wr = tab.w[l] + (int64_t)(n0 + r16) * D + kb;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) wcur[s] = *reinterpret_cast<const ad_u32x4*>(wr + 32 * s);
+  }
+  {   // stage the row group: 16-byte chunks, 12 per thread per pass
+    constexpr int CPR = D / 8;                                    // chunks per row
+    const int nch = nr * CPR;
+    for (int e0 = 0; e0 < nch; e0 += 256 * 12) {
+      ad_u32x4 v[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int e = min(e0 + tid + 256 * i, nch - 1);
+        const int r = e / CPR, cc = e - r * CPR;
+        v[i] = *reinterpret_cast<const ad_u32x4*>(c + (int64_t)(m0 + r) * D + 8 * cc);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int e = e0 + tid + 256 * i;
+        if (e < nch) { const int r = e / CPR, cc = e - r * CPR; *reinterpret_cast<ad_u32x4*>(xs + r * P + 8 * cc) = v[i]; }
+      }
+    }
+  }
+  __syncthreads();
+  const bf16_t* xf[NM];
+#pragma unroll
+  for (int t = 0; t < NM; ++t) xf[t] = xs + min(16 * t + r16, nr - 1) * P + kb;
+  const int ei = tid >> 6, el = tid & 63;
+  int par = 0;
+  for (; bx < total; bx += gridDim.x) {
+    const int bn = bx + gridDim.x;
+    if (bn < total) {
+      int l2, n2;
+      locate(bn, l2, n2);
+      const bf16_t* wr = tab.w[l2] + (int64_t)(n2 + r16) * D + kb;
+#pragma unroll
+      for (int s = 0; s < NST; ++s) wnxt[s] = *reinterpret_cast<const ad_u32x4*>(wr + 32 * s);
+    }
+    ad_f32x4 acc[NM];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) acc[t] = ad_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NST; ++s)
+#pragma unroll
+      for (int t = 0; t < NM; ++t) {
+        const ad_u32x4 xb = *reinterpret_cast<const ad_u32x4*>(xf[t] + 32 * s);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ad_bf16x8, wcur[s]), __builtin_bit_cast(ad_bf16x8, xb), acc[t], 0, 0, 0);
+      }
+    float* rp = red + par * (4 * NM * 4 * 64);
+#pragma unroll
+    for (int t = 0; t < NM; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rp[((wave * NM + t) * 4 + i) * 64 + lane] = acc[t][i];
+    __syncthreads();                     // one barrier per block: the partials alternate between two buffers
+    locate(bx, l, n0);
+    float* out = tab.out[l];
+    const int ldo = tab.ldo[l];
+#pragma unroll
+    for (int t = 0; t < NM; ++t) {
+      const int m = 16 * t + (el & 15);
+      if (m < nr) {
+        float v = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) v += rp[((w4 * NM + t) * 4 + ei) * 64 + el];      // fixed order: deterministic
+        out[(int64_t)(m0 + m) * ldo + n0 + 4 * (el >> 4) + ei] = v;
+      }
+    }
+    par ^= 1;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) wcur[s] = wnxt[s];
   }
 }
 
@@ -303,6 +545,18 @@ extern "C" int vv_llm_tail(const vv_llm* m, const float* h, int64_t ldh, int R, 
   if (R <= 0 || nv <= 0 || nv > 16) return vv_set_error(VV_E_ARG, "vv_llm_tail: R=%d nv=%d (nv <= 16)", R, nv);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)m->hidden * sizeof(float);
+  auto a16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  if (R <= 2 && nv <= 8 && m->hidden % 4 == 0 && m->hidden <= 4096 && a16(h) && ldh % 4 == 0 && a16(out) && ldo % 4 == 0 && a16(m->final_norm) &&
+      ((uintptr_t)w_valid % (m->wdt == VV_F32 ? 16 : 8)) == 0 && (m->wdt == VV_F32 || m->hidden % 4 == 0)) {
+    if (m->wdt == VV_F32)
+      hipLaunchKernelGGL((llm_tail_fast_kernel<float>), dim3(1), dim3(256), 0, s, h, ldh, R, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const float*)w_valid, nv,
+                         ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter);
+    else
+      hipLaunchKernelGGL((llm_tail_fast_kernel<bf16_t>), dim3(1), dim3(256), 0, s, h, ldh, R, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const bf16_t*)w_valid,
+                         nv, ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter);
+    VV_CHECK_LAUNCH("vv_llm_tail");
+    return 0;
+  }
   if (m->wdt == VV_F32)
     hipLaunchKernelGGL((llm_tail_kernel<float>), dim3(1), dim3(256), lds, s, h, ldh, R, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const float*)w_valid, nv, ids,
                        logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter);
@@ -329,4 +583,37 @@ int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStre
   else hipLaunchKernelGGL(conv_ctx_gather_kernel, dim3(bx, n), dim3(256), 0, s, a);
   VV_CHECK_LAUNCH("vv_conv_ctx_batch");
   return 0;
+}
+
+static constexpr size_t ADA_LDS = (size_t)40 * (1536 + 8) * 2 + (size_t)2 * 4 * 3 * 4 * 64 * 4;
+
+int vv_fused_init() {     // before any graph capture
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&adaln_lds_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ADA_LDS) != hipSuccess)
+    return vv_set_error(VV_E_HIP, "vv_fused_init: cannot raise the LDS limit");
+  return 0;
+}
+
+// 1 = launched, 0 = not covered (caller runs one vv_linear per matrix)
+int vv_head_modulations_fused(const vv_head* h, const void* c_bf16, int rows, float* const* mod, float* modf, hipStream_t s) {
+  const int D = h->D;
+  if (h->wdt != VV_BF16 || h->layers > 16 || rows < 1 || ((uintptr_t)c_bf16 % 16) || ((uintptr_t)h->final_adaln % 16)) return 0;
+  if (D != 4 * 32 * 12 && D != 4 * 32 * 28) return 0;
+  AdaTab tab;
+  int total = 0;
+  for (int l = 0; l < h->layers; ++l) {
+    if ((uintptr_t)h->layer[l].adaln % 16) return 0;
+    tab.w[l] = reinterpret_cast<const bf16_t*>(h->layer[l].adaln); tab.out[l] = mod[l]; tab.nblk[l] = 3 * D / 16; tab.ldo[l] = 3 * D;
+    total += tab.nblk[l];
+  }
+  const int f = h->layers;
+  tab.w[f] = reinterpret_cast<const bf16_t*>(h->final_adaln); tab.out[f] = modf; tab.nblk[f] = 2 * D / 16; tab.ldo[f] = 2 * D;
+  total += tab.nblk[f];
+  tab.n = f + 1;
+  for (int l = tab.n; l < 17; ++l) { tab.w[l] = nullptr; tab.out[l] = nullptr; tab.nblk[l] = 0; tab.ldo[l] = 0; }
+  const bf16_t* c = reinterpret_cast<const bf16_t*>(c_bf16);
+  if (D == 4 * 32 * 12) hipLaunchKernelGGL((adaln_lds_kernel<12>), dim3(total < 256 ? total : 256, (rows + 39) / 40), dim3(256), ADA_LDS, s, c, rows, tab, total);
+  else hipLaunchKernelGGL((adaln_all_kernel<28, 1>), dim3(total, (rows + 15) / 16), dim3(256), 0, s, c, rows, D, tab);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_modulations_fused: %s", hipGetErrorString(e));
+  return 1;
 }

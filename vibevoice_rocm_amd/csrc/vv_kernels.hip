@@ -36,6 +36,7 @@ extern "C" int vv_init(void) {
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
   VV_TRY(vv_convffn_init());
+  VV_TRY(vv_fused_init());
   return vv_chain_init();
 }
 void vv_gemv_stream_set_blocks(int b);

@@ -193,6 +193,10 @@ static int head_body(const vv_head* h, const float* x, int64_t ldx, int R, float
 // matrix-core path would round to anyway; the >= 32-tile adaLN GEMMs then run on the LDS-tiled kernel)
 static int head_modulations(const vv_head* h, const float* c, int rows, float* const* mod, float* modf, bool presilu, bool c_bf16, vv_stream_t stream) {
   const int D = h->D;
+  if (presilu && c_bf16) {     // the per-frame form (rows = 2 * n_steps bf16 conditioning rows): every matrix in one launch (vv_fused.hip)
+    const int one = vv_head_modulations_fused(h, c, rows, mod, modf, (hipStream_t)stream);
+    if (one) return one < 0 ? one : 0;
+  }
   for (int l = 0; l < h->layers; ++l) {
     vv_lin_args a = lin_base(c, D, rows, h->layer[l].adaln, 3 * D, D, h->wdt, mod[l], 3 * D);
     a.pro = presilu ? VV_PRO_NONE : VV_PRO_SILU;
