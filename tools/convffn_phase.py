@@ -1,0 +1,57 @@
+"""Phase timing of ffn_in_kernel (vv_convffn.hip) on the middle-stage shapes of a streaming frame.  Builds a debug copy of the library with
+-DVV_CF_TIMING into tools/bin (the product library carries no stamps) and runs vv_block_mid on it.
+
+  python tools/convffn_phase.py build     (CPU container or GPU box)
+  python tools/convffn_phase.py run       (GPU box)"""
+import ctypes as C, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tools", "bin", "libvv_hip_cft.so")
+
+
+def build():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    src = [f for f in sorted(glob.glob(os.path.join(ROOT, "vibevoice_rocm_amd", "csrc", "*.hip"))) if not f.endswith("vv_chain.hip")]
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DVV_CF_TIMING", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "vibevoice_rocm_amd", "csrc")] + src + ["-o", SO]
+    subprocess.check_call(cmd)
+
+
+def run():
+    import torch
+    sys.path.insert(0, ROOT)
+    from vibevoice_rocm_amd import _lib as L
+    lib = C.CDLL(SO)
+    assert lib.vv_init() == 0
+    lib.vv_block_mid_ws_bytes.restype = C.c_size_t
+    for C_, T, rows in ((512, 40, 32), (512, 40, 16), (512, 40, 8), (256, 200, 32), (256, 200, 16), (256, 200, 8), (1024, 8, 8)):
+        if C_ != 1024:
+            lib.vv_tune(f"convffn_rows{C_}".encode(), rows)
+        g = torch.Generator().manual_seed(1)
+        r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+        p = dict(gamma=r(C_, sc=0.5), ffn_gamma=r(C_, sc=0.5), norm_w=1 + r(C_, sc=0.1), ffn_norm_w=1 + r(C_, sc=0.1), dw_w=r(C_, 7, sc=0.3), dw_b=r(C_, sc=0.1),
+                 w1=(r(4 * C_, C_) / C_ ** 0.5).bfloat16(), b1=r(4 * C_, sc=0.1), w2=(r(C_, 4 * C_) / (4 * C_) ** 0.5).bfloat16(), b2=r(C_, sc=0.1))
+        hist = torch.zeros(6, C_, device="cuda")
+        b = L.Block()
+        for k, v in p.items():
+            setattr(b, k, v.data_ptr())
+        b.hist = hist.data_ptr()
+        ws = torch.empty(lib.vv_block_mid_ws_bytes(T, C_), dtype=torch.uint8, device="cuda")
+        x, o = r(T, C_), torch.empty(T, C_, device="cuda")
+        t = (C.c_ulonglong * 8)()
+        call = lambda: lib.vv_block_mid(C.byref(b), L.VV_BF16, C.c_void_p(x.data_ptr()), C.c_void_p(o.data_ptr()), C.c_void_p(ws.data_ptr()), T, C_, C.c_float(1e-5), None)
+        for _ in range(5):
+            assert call() == 0
+        torch.cuda.synchronize()
+        lib.vv_convffn_debug_times(t, 1)
+        n = 200
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        lib.vv_convffn_debug_times(t, 1)
+        names = ["issue", "loads+stat1", "xn->LDS", "conv+stat2", "xh+y", "mfma", "epilogue"]
+        ns = [t[i] * 10.0 / n for i in range(7)]          # wall_clock64: 100 MHz
+        print(f"C={C_} T={T} tile {rows}: " + "  ".join(f"{nm} {v:6.0f} ns" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us", flush=True)
+
+
+if __name__ == "__main__":
+    (build if sys.argv[1:] == ["build"] else run)()

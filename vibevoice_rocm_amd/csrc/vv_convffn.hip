@@ -32,6 +32,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// phase timing of workgroup (0, 0) / thread 0, debug builds only (-DVV_CF_TIMING, tools/convffn_phase.py)
+#ifdef VV_CF_TIMING
+__device__ unsigned long long g_cf_t[8];
+#define CSTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); g_cf_t[i] += (unsigned long long)(t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+
 constexpr int TR2 = 16;         // rows per workgroup of ffn_out (one 16 x 16 MFMA tile)
 constexpr int HALO = 6;         // causal depthwise kernel 7
 
@@ -42,31 +50,43 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 __device__ __forceinline__ float sq4(const float4 v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 
 template <int C, int TRV> struct InLay {                  // TRV: sequence rows per workgroup (<= 32; the MFMA tile stays 32 wide)
-  static constexpr int F4 = C / 4;                        // float4 columns per row = threads per row
-  static constexpr int RP = 256 / F4;                     // window rows per pass of the 256 threads
+  static constexpr int F4 = C / 4;                        // float4 columns per row
+  static constexpr int TPR = F4 < 256 ? F4 : 256;         // threads per row
+  static constexpr int CPT = F4 / TPR;                    // float4 columns per thread per row (2 at C = 2048)
+  static constexpr int RP = 256 / TPR;                    // window rows per pass of the 256 threads
   static constexpr int NI = (TRV + HALO + RP - 1) / RP;   // passes over the window (TRV + 6 rows)
-  static constexpr int WPR = F4 / 64;                     // waves per row (partial sums of squares per row)
+  static constexpr int WR = NI * RP;                      // window rows held in LDS (>= TRV + 6: no row guards on the LDS side)
+  static constexpr int WPR = TPR / 64;                    // waves per row (partial sums of squares per row)
   static constexpr int P1 = C + 8;                        // bf16 pitch of the FFN input image
   static constexpr int ST = C / 64;                       // MFMA steps of one wave (K split over the 4 waves)
-  static constexpr size_t XN = (size_t)(TRV + HALO) * C * 4;
+  static constexpr size_t XN = (size_t)WR * C * 4;
   static constexpr size_t RED = (size_t)4 * 16 * 64 * 4;  // K-split partial accumulators (alias the window once it is consumed)
-  static constexpr size_t XH = (size_t)TRV * P1 * 2;
-  static constexpr size_t PART = (size_t)2 * (TRV + HALO) * 4 * 4;
+  static constexpr size_t XH = (size_t)(WR - HALO) * P1 * 2;
+  static constexpr size_t PART = (size_t)2 * WR * 4 * 4;
   static constexpr size_t LDS = (XN > RED ? XN : RED) + XH + PART;
 };
 
-template <int C, int TRV>
-__global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ hidden,
+__device__ __forceinline__ float4 mul4(const float4 a, const float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+// HF32: the hidden tile is written in fp32 (the T = 1 stage, whose second GEMM stays on the weight-streaming GEMV)
+template <int C, int TRV, bool HF32>
+__global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, void* __restrict__ hidden_v,
                                                      float* __restrict__ hist_new, int T, const vv_block B, float eps) {
   using L = InLay<C, TRV>;
-  constexpr int TR = TRV;
+  constexpr int TR = TRV, CPT = L::CPT;
+#ifdef VV_CF_TIMING
+  long long tprev_ = wall_clock64();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* xn = reinterpret_cast<float*>(smem);                                        // [TR + 6][C] normalised window
+  float* xn = reinterpret_cast<float*>(smem);                                        // [WR][C] normalised window
   float* red = reinterpret_cast<float*>(smem);                                       // aliases xn after the conv
-  bf16_t* xh = reinterpret_cast<bf16_t*>(smem + (L::XN > L::RED ? L::XN : L::RED));  // [TR][P1] RMSNorm(y) in bf16
-  float* part = reinterpret_cast<float*>(smem + (L::XN > L::RED ? L::XN : L::RED) + L::XH);   // [2][TR + 6][4]
-  float* part2 = part + (TR + HALO) * 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16_t* xh = reinterpret_cast<bf16_t*>(smem + (L::XN > L::RED ? L::XN : L::RED));  // [WR - 6][P1] RMSNorm(y) in bf16
+  float* part = reinterpret_cast<float*>(smem + (L::XN > L::RED ? L::XN : L::RED) + L::XH);   // [2][WR][4]
+  float* part2 = part + L::WR * 4;
+  // The wave index goes through readfirstlane: everything derived from it (window row, validity, LDS rows) is then wave-uniform for the
+  // compiler - scalar address arithmetic and scalar selects.  The mixer part of this kernel is bound by instruction issue (one wave per
+  // SIMD, tools/convffn_phase.py), so guards are written as selects / 0-1 factors on always-valid addresses, not as branches.
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * 32;
   const int t0 = blockIdx.y * TR;
   const int rows = min(TR, T - t0);
@@ -79,73 +99,95 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 #pragma unroll
     for (int s = 0; s < L::ST; ++s) wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
   }
-  const int cq = tid % L::F4, rloc = tid / L::F4, c0 = cq * 4;
-  const int slot = wave % L::WPR;
-  float4 own[L::NI];
+  const int rloc = wave / L::WPR, slot = wave % L::WPR;            // TPR >= 64: a wave sits inside one window row
+  int c0[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) c0[j] = 4 * (tid % L::TPR + L::TPR * j);
+  const float* hb = B.hist ? B.hist : x;                           // history rows of a stateless call read x row 0 and are zeroed below
+  const float hkeep = B.hist ? 1.f : 0.f;
+  float4 own[L::NI][CPT];
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i, t = t0 - HALO + w;
-    own[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (w < rows + HALO) {
-      if (t >= 0) own[i] = *reinterpret_cast<const float4*>(x + (int64_t)t * C + c0);
-      else if (B.hist) own[i] = *reinterpret_cast<const float4*>(B.hist + (int64_t)(HALO + t) * C + c0);     // already normalised
+    const bool isx = t >= 0;
+    const float* src = isx ? x + (int64_t)min(t, T - 1) * C : hb + (int64_t)(B.hist ? HALO + t : 0) * C;
+    const float keep = (w < rows + HALO) ? (isx ? 1.f : hkeep) : 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) own[i][j] = mul4(*reinterpret_cast<const float4*>(src + c0[j]), keep);
+  }
+  float4 nw[CPT], db[CPT], gm[CPT], fw[CPT];
+  float tap[CPT][28];                                              // tap[j][7 c + k] of channels c0[j] .. c0[j] + 3
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    nw[j] = *reinterpret_cast<const float4*>(B.norm_w + c0[j]);
+    db[j] = *reinterpret_cast<const float4*>(B.dw_b + c0[j]);
+    gm[j] = *reinterpret_cast<const float4*>(B.gamma + c0[j]);
+    fw[j] = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0[j]);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const float4 tq = *reinterpret_cast<const float4*>(B.dw_w + (size_t)c0[j] * 7 + 4 * q);
+      tap[j][4 * q] = tq.x; tap[j][4 * q + 1] = tq.y; tap[j][4 * q + 2] = tq.z; tap[j][4 * q + 3] = tq.w;
     }
   }
-  const float4 nw = *reinterpret_cast<const float4*>(B.norm_w + c0);
-  const float4 db = *reinterpret_cast<const float4*>(B.dw_b + c0);
-  const float4 gm = *reinterpret_cast<const float4*>(B.gamma + c0);
-  const float4 fw = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0);
-  float tap[28];                                                   // tap[7 c + k] of channels c0 .. c0 + 3
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const float4 tq = *reinterpret_cast<const float4*>(B.dw_w + (size_t)c0 * 7 + 4 * q);
-    tap[4 * q] = tq.x; tap[4 * q + 1] = tq.y; tap[4 * q + 2] = tq.z; tap[4 * q + 3] = tq.w;
-  }
-  const int eg = tid >> 6;                                         // epilogue: this thread finishes channels n0 + 8 eg + 4 (lane >> 5) + {0..3}
+  const int eg = wave;                                             // epilogue: this thread finishes channels n0 + 8 eg + 4 (lane >> 5) + {0..3}
   const float4 b1v = *reinterpret_cast<const float4*>(B.b1 + n0 + 8 * eg + 4 * (lane >> 5));
 
+  CSTAMP(0);                                       // address arithmetic + load issue
   // ---- 1. RMS statistic of the window rows ------------------------------------------------------------------------------------
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i;
-    const float s = vv_wave_sum(sq4(own[i]));
-    if (lane == 0 && w < TR + HALO) part[w * 4 + slot] = s;
+    float q = sq4(own[i][0]);
+#pragma unroll
+    for (int j = 1; j < CPT; ++j) q += sq4(own[i][j]);
+    const float s = vv_wave_sum(q);
+    if (lane == 0) part[w * 4 + slot] = s;
   }
   __syncthreads();
+  CSTAMP(1);                                       // loads landed, row statistics, barrier
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i, t = t0 - HALO + w;
-    if (w < TR + HALO) {
-      float4 v = own[i];
-      if (t >= 0 && w < rows + HALO) {
-        float ss = part[w * 4];
+    float ss = part[w * 4];
 #pragma unroll
-        for (int sl = 1; sl < L::WPR; ++sl) ss += part[w * 4 + sl];
-        const float rstd = rsqrtf(ss / (float)C + eps);
-        v.x *= rstd * nw.x; v.y *= rstd * nw.y; v.z *= rstd * nw.z; v.w *= rstd * nw.w;
-      }
-      *reinterpret_cast<float4*>(xn + w * C + c0) = v;
+    for (int sl = 1; sl < L::WPR; ++sl) ss += part[w * 4 + sl];
+    const bool isx = t >= 0;                                       // history rows are stored normalised; rows past the sequence are zeros
+    const float rstd = isx ? rsqrtf(ss / (float)C + eps) : 1.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const float4 ww = isx ? nw[j] : make_float4(1.f, 1.f, 1.f, 1.f);
+      *reinterpret_cast<float4*>(xn + w * C + c0[j]) =
+          make_float4(own[i][j].x * rstd * ww.x, own[i][j].y * rstd * ww.y, own[i][j].z * rstd * ww.z, own[i][j].w * rstd * ww.w);
     }
   }
   __syncthreads();
+  CSTAMP(2);                                       // normalised window to LDS
 
   // ---- 2. mixer, then the FFN's RMS statistic ------------------------------------------------------------------------------------
-  float4 y1[L::NI];
+  float4 y1[L::NI][CPT];
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) y1[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (L::RP * i + L::RP - 1 < HALO) continue;                    // (compile time) halo rows only: no output row in this pass
     const int w = rloc + L::RP * i, tt = w - HALO;
-    y1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tt >= 0 && tt < rows) {
-      float4 s = db;
+    const int tc = max(tt, 0);
+    const float ok = (tt >= 0 && tt < rows) ? 1.f : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      float4 s = db[j];
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(xn + (tt + k) * C + c0);
-        s.x = fmaf(tap[k], v.x, s.x); s.y = fmaf(tap[7 + k], v.y, s.y); s.z = fmaf(tap[14 + k], v.z, s.z); s.w = fmaf(tap[21 + k], v.w, s.w);
+        const float4 v = *reinterpret_cast<const float4*>(xn + (tc + k) * C + c0[j]);
+        s.x = fmaf(tap[j][k], v.x, s.x); s.y = fmaf(tap[j][7 + k], v.y, s.y); s.z = fmaf(tap[j][14 + k], v.z, s.z); s.w = fmaf(tap[j][21 + k], v.w, s.w);
       }
-      y1[i] = make_float4(own[i].x + gm.x * s.x, own[i].y + gm.y * s.y, own[i].z + gm.z * s.z, own[i].w + gm.w * s.w);
+      y1[i][j] = make_float4((own[i][j].x + gm[j].x * s.x) * ok, (own[i][j].y + gm[j].y * s.y) * ok, (own[i][j].z + gm[j].z * s.z) * ok,
+                             (own[i][j].w + gm[j].w * s.w) * ok);
+      q += sq4(y1[i][j]);
     }
-    const float s2 = vv_wave_sum(sq4(y1[i]));
-    if (lane == 0 && w < TR + HALO) part2[w * 4 + slot] = s2;
+    const float s2 = vv_wave_sum(q);
+    if (lane == 0) part2[w * 4 + slot] = s2;
   }
   // the new streaming history = the last 6 rows of [old history ; normalised rows]: all inside the LAST row tile's window
   if (hist_new && blockIdx.x == 0 && t0 + TR >= T) {
@@ -155,27 +197,33 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
     }
   }
   __syncthreads();
+  CSTAMP(3);                                       // conv + second statistic
   {
     const int ys0 = blockIdx.x * (C / (int)gridDim.x);              // this workgroup's columns of y
-    const bool mine = c0 >= ys0 && c0 < ys0 + C / (int)gridDim.x;
 #pragma unroll
     for (int i = 0; i < L::NI; ++i) {
+      if (L::RP * i + L::RP - 1 < HALO) continue;
       const int w = rloc + L::RP * i, tt = w - HALO;
-      if (tt >= 0 && tt < TR) {                                      // rows past the end of the sequence: zeros
+      if (tt >= 0) {                                                // (wave-uniform; rows past the end of the sequence hold zeros)
         float ss = part2[w * 4];
 #pragma unroll
         for (int sl = 1; sl < L::WPR; ++sl) ss += part2[w * 4 + sl];
         const float rstd = rsqrtf(ss / (float)C + eps);
-        uint2 p;
-        p.x = pack2(y1[i].x * rstd * fw.x, y1[i].y * rstd * fw.y);
-        p.y = pack2(y1[i].z * rstd * fw.z, y1[i].w * rstd * fw.w);
-        *reinterpret_cast<uint2*>(xh + tt * L::P1 + c0) = p;
-        if (mine && tt < rows) *reinterpret_cast<float4*>(y + (int64_t)(t0 + tt) * C + c0) = y1[i];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          uint2 p;
+          p.x = pack2(y1[i][j].x * rstd * fw[j].x, y1[i][j].y * rstd * fw[j].y);
+          p.y = pack2(y1[i][j].z * rstd * fw[j].z, y1[i][j].w * rstd * fw[j].w);
+          *reinterpret_cast<uint2*>(xh + tt * L::P1 + c0[j]) = p;
+          const bool mine = c0[j] >= ys0 && c0[j] < ys0 + C / (int)gridDim.x;
+          if (mine && tt < rows) *reinterpret_cast<float4*>(y + (int64_t)(t0 + tt) * C + c0[j]) = y1[i][j];
+        }
       }
     }
   }
   __syncthreads();
 
+  CSTAMP(4);                                       // bf16 image + y slice
   // ---- 3. hidden tile = gelu(W1 xh + b1): 32 channels x 32 rows, K split over the waves -------------------------------------------
   f32x16 acc;
 #pragma unroll
@@ -191,6 +239,7 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];      // xn is dead: every read of it sits before the last barrier
   __syncthreads();
+  CSTAMP(5);                                       // MFMA + partials
   {
     const int m = lane & 31;
     if (m < rows) {
@@ -202,12 +251,19 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
         for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 16 + 4 * eg + i) * 64 + lane];   // fixed order: deterministic
         v[i] = s;
       }
-      uint2 p;
-      p.x = pack2(vv_gelu_as(v[0] + b1v.x), vv_gelu_as(v[1] + b1v.y));
-      p.y = pack2(vv_gelu_as(v[2] + b1v.z), vv_gelu_as(v[3] + b1v.w));
-      *reinterpret_cast<uint2*>(hidden + (int64_t)(t0 + m) * (4 * C) + n0 + 8 * eg + 4 * (lane >> 5)) = p;
+      const float g0 = vv_gelu_as(v[0] + b1v.x), g1 = vv_gelu_as(v[1] + b1v.y), g2 = vv_gelu_as(v[2] + b1v.z), g3 = vv_gelu_as(v[3] + b1v.w);
+      const int64_t ho = (int64_t)(t0 + m) * (4 * C) + n0 + 8 * eg + 4 * (lane >> 5);
+      if (HF32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(hidden_v) + ho) = make_float4(g0, g1, g2, g3);
+      } else {
+        uint2 p;
+        p.x = pack2(g0, g1);
+        p.y = pack2(g2, g3);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(hidden_v) + ho) = p;
+      }
     }
   }
+  CSTAMP(6);                                       // combine + GELU + store
 }
 
 // out[T, C] = res + ffn_gamma * (W2 hidden + b2), hidden bf16 [T, 4C]
@@ -321,14 +377,27 @@ template <int C, int TRV, int NW>
 int launch_c(const vv_block& B, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, float eps, hipStream_t s) {
   float* hn = B.hist ? hist_new : nullptr;
   constexpr size_t lds = InLay<C, TRV>::LDS;
-  hipLaunchKernelGGL((ffn_in_kernel<C, TRV>), dim3(4 * C / 32, (T + TRV - 1) / TRV), dim3(256), lds, s, x, y, reinterpret_cast<bf16_t*>(hidden), hn, T, B, eps);
+  hipLaunchKernelGGL((ffn_in_kernel<C, TRV, false>), dim3(4 * C / 32, (T + TRV - 1) / TRV), dim3(256), lds, s, x, y, hidden, hn, T, B, eps);
   hipLaunchKernelGGL((ffn_out_kernel<C, NW>), dim3(C / 16, (T + TR2 - 1) / TR2), dim3(64 * NW), 0, s, reinterpret_cast<const bf16_t*>(hidden), y, out, hn, T, B);
   return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
 }
 
+// rows per workgroup of ffn_in.  Every hidden block of a row tile recomputes the tile's mixer, and with one wave per SIMD that part is
+// bound by instruction issue (tools/convffn_phase.py: 9 of 12 us at C = 512 with 32-row tiles): short tiles cut it, at the price of
+// re-reading W1 once per tile from L2.
+int g_trv512 = 8, g_trv256 = 16;
+
 }  // namespace
 
+#ifdef VV_CF_TIMING
+extern "C" int vv_convffn_debug_times(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cf_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cf_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 void vv_convffn_set(int on) { g_on = on; }
+void vv_convffn_set_rows(int c, int rows) { if (c == 512) g_trv512 = rows; else if (c == 256) g_trv256 = rows; }
 void vv_skinny_set(int on, int min_m, int max_m) { g_skinny = on; if (min_m > 0) g_skinny_min_m = min_m; if (max_m > 0) g_skinny_max_m = max_m; }
 
 // 1 = launched, 0 = not covered
@@ -350,12 +419,35 @@ int vv_launch_skinny(const vv_lin_args& a, hipStream_t s) {
 }
 
 int vv_convffn_init() {
-  constexpr int l256 = (int)InLay<256, 32>::LDS, l512 = (int)InLay<512, 32>::LDS, l1024 = (int)InLay<1024, 8>::LDS;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<256, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, l256) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<512, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, l512) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<1024, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, l1024) != hipSuccess)
-    return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit");
+#define VV_CF_ATTR(CC, TT)                                                                                                                  \
+  { constexpr int l_ = (int)InLay<CC, TT>::LDS;                                                                                            \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<CC, TT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, l_) != hipSuccess) \
+      return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit"); }
+  VV_CF_ATTR(256, 8) VV_CF_ATTR(256, 16) VV_CF_ATTR(256, 32) VV_CF_ATTR(512, 8) VV_CF_ATTR(512, 16) VV_CF_ATTR(512, 32) VV_CF_ATTR(1024, 8)
+#undef VV_CF_ATTR
+  {
+    constexpr int l1 = (int)InLay<2048, 1>::LDS;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<2048, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess)
+      return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit");
+  }
   return 0;
+}
+
+int g_t1 = 1;
+void vv_convffn_set_t1(int on) { g_t1 = on; }
+
+// The first FFN half of a Block1D of the ONE-row stage (C = 2048, one row per frame): mixer + RMSNorm + W1 + GELU in one launch, hidden row
+// in fp32 for the weight-streaming GEMV that follows; the new history goes to hist_new (6 * C floats of scratch that must survive until the
+// caller has moved it into b.hist, after every workgroup of this launch is done).  1 = enqueued, 0 = not covered
+int vv_launch_ffn_in_row(const vv_block& B, int wdt, const float* x, float* y, float* hidden, float* hist_new, int C, float eps, hipStream_t s) {
+  if (!g_on || !g_t1 || wdt != VV_BF16 || C != 2048 || !B.hist) return 0;
+  auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
+  if (!a16(B.w1) || !a16(B.b1) || !a16(B.gamma) || !a16(B.norm_w) || !a16(B.ffn_norm_w) || !a16(B.dw_b) || !a16(B.dw_w) || !a16(x) || !a16(y) ||
+      !a16(hidden) || !a16(hist_new) || !a16(B.hist) || x == y)
+    return 0;
+  constexpr size_t lds = InLay<2048, 1>::LDS;
+  hipLaunchKernelGGL((ffn_in_kernel<2048, 1, true>), dim3(4 * 2048 / 32, 1), dim3(256), lds, s, x, y, hidden, hist_new, 1, B, eps);
+  return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
 }
 
 // One Block1D of a middle stage: x[T, C] -> y[T, C] (mixer output, also the FFN residual) -> hidden (bf16 [T, 4C]) -> out[T, C]
@@ -371,8 +463,16 @@ int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void
     const uintptr_t xa = (uintptr_t)x, ya = (uintptr_t)y, bytes = (uintptr_t)T * C * 4;
     if (xa < ya + bytes && ya < xa + bytes) return 0;
   }
-  if (C == 256) return launch_c<256, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
-  if (C == 512) return launch_c<512, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+  if (C == 256) {
+    if (g_trv256 == 8) return launch_c<256, 8, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+    if (g_trv256 == 16) return launch_c<256, 16, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+    return launch_c<256, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+  }
+  if (C == 512) {
+    if (g_trv512 == 8) return launch_c<512, 8, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+    if (g_trv512 == 16) return launch_c<512, 16, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+    return launch_c<512, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+  }
   return launch_c<1024, 8, 8>(B, x, y, hidden, hist_new, out, T, eps, s);     // T = 8 rows per frame: 8-row tiles, K = 4096 over 8 waves
 }
 

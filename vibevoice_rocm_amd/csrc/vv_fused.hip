@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int6
 // streaming conv contexts of a whole tokenizer
 // ---------------------------------------------------------------------------------------------------------------
 struct CtxItem { float* pad; float* state; int ctx, T, C; };
-struct CtxArgs { CtxItem it[VV_MAX_STAGES + 1]; int n; };
+struct CtxArgs { CtxItem it[VV_MAX_STAGES + 1 + 16]; int n; };   // convs of a net + the one-row stage's block histories (vv_model.hip)
 
 // gather: pad[0 : ctx] <- state for every conv (before any of them runs)
 __global__ __launch_bounds__(256) void conv_ctx_gather_kernel(const CtxArgs a) {
@@ -569,7 +569,7 @@ extern "C" int vv_llm_tail(const vv_llm* m, const float* h, int64_t ldh, int R, 
 
 int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStream_t s) {
   if (n <= 0) return 0;
-  if (n > VV_MAX_STAGES + 1) return vv_set_error(VV_E_ARG, "vv_conv_ctx_batch: too many convs");
+  if (n > VV_MAX_STAGES + 1 + 16) return vv_set_error(VV_E_ARG, "vv_conv_ctx_batch: too many items");
   CtxArgs a;
   a.n = n;
   int mx = 0;

@@ -64,6 +64,9 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
+  if (key && !strcmp(key, "convffn_t1")) { vv_convffn_set_t1(value); return 0; }
+  if (key && !strcmp(key, "convffn_rows512")) { vv_convffn_set_rows(512, value); return 0; }
+  if (key && !strcmp(key, "convffn_rows256")) { vv_convffn_set_rows(256, value); return 0; }
   if (key && !strcmp(key, "skinny")) { vv_skinny_set(value, 0, 0); return 0; }
   if (key && !strcmp(key, "skinny_min_m")) { vv_skinny_set(1, value, 0); return 0; }
   if (key && !strcmp(key, "skinny_max_m")) { vv_skinny_set(1, 0, value); return 0; }
@@ -1668,8 +1671,30 @@ __global__ void copy_rows_kernel(const float* x, int64_t ldx, float* out, int64_
   const int r = blockIdx.y;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) out[(int64_t)r * ldo + c] = x[(int64_t)r * ldx + c];
 }
+// long rows (the streaming-state snapshot of a speculative frame: ~1 MB in one row): 16-byte accesses, 4 per thread in flight, enough
+// workgroups to pull from every CU (64 workgroups of scalar loads took 10 us for it)
+__global__ __launch_bounds__(256) void copy_rows4_kernel(const float4* x, int64_t ldx4, float4* out, int64_t ldo4, int n4) {
+  const int r = blockIdx.y;
+  const float4* xr = x + (int64_t)r * ldx4;
+  float4* orow = out + (int64_t)r * ldo4;
+  const int c0 = (blockIdx.x * 256 + threadIdx.x), st = gridDim.x * 256;
+  for (int c = c0; c < n4; c += 4 * st) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = xr[min(c + i * st, n4 - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (c + i * st < n4) orow[c + i * st] = v[i];
+  }
+}
 extern "C" int vv_copy_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int rows, int n, vv_stream_t stream) {
   if (!x || !out || rows <= 0 || n <= 0) return vv_set_error(VV_E_ARG, "vv_copy_rows: bad args");
+  if (n >= 16384 && n % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && rows <= 65535) {
+    int b4 = (n / 4 + 1023) / 1024; if (b4 > 1024) b4 = 1024;
+    hipLaunchKernelGGL(copy_rows4_kernel, dim3(b4, rows), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), ldx / 4,
+                       reinterpret_cast<float4*>(out), ldo / 4, n / 4);
+    VV_CHECK_LAUNCH("vv_copy_rows");
+    return 0;
+  }
   int bx = (n + 255) / 256; if (bx > 64) bx = 64;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(bx, rows), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, n);
   VV_CHECK_LAUNCH("vv_copy_rows");

@@ -355,11 +355,15 @@ static size_t convnet_pad_floats(const vv_convnet* net, int64_t t_in, size_t* of
   return tot;
 }
 
+// scratch histories of the one-row stage's blocks (<= 16 blocks x 6 rows x 2048 channels), see run_blocks
+#define VV_ROW_BLOCKS 16
+#define VV_ROW_HIST_FLOATS ((size_t)VV_ROW_BLOCKS * 6 * 2048)
+
 extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int decoder) {
   if (!net || t_in <= 0) return 0;
   size_t a, h;
   convnet_sizes(net, t_in, decoder, &a, &h);
-  return 2 * al(a) + al(h) + (convnet_streaming(net) ? al(convnet_pad_floats(net, t_in, nullptr)) : 0);
+  return 2 * al(a) + al(h) + (convnet_streaming(net) ? al(convnet_pad_floats(net, t_in, nullptr)) + al(VV_ROW_HIST_FLOATS) : 0);
 }
 
 // Runs the stage's blocks on the ping-pong buffers cur / other.  The LAST block writes its result `nctx` rows into a buffer so
@@ -367,7 +371,10 @@ extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int d
 // dead input buffer is the only one free, so the result goes there, shifted.  Fused block (one launch reads its input while
 // other row tiles already write): the result must not overlap the input; `other` is free (no mixer output) and takes it.
 static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*& cur, float*& other, float* hid,
-                      int nctx, float** pad_out, vv_stream_t stream, float* next_pad = nullptr) {
+                      int nctx, float** pad_out, vv_stream_t stream, float* next_pad = nullptr, float* row_hist = nullptr,
+                      vv_conv_ctx_item* items = nullptr, int* n_items = nullptr) {
+  // row_hist / items (streaming nets): scratch for the new histories of the one-row stage's blocks and the list of state moves that the
+  // net's closing vv_conv_ctx_batch performs (a block's history may only be replaced once every workgroup that reads it is done)
   // next_pad (streaming nets): the next conv's own padded-input region; the stage result goes to next_pad + nctx rows
   const int nb = net->n_blocks[stage];
   for (int j = 0; j < nb; ++j) {
@@ -385,6 +392,23 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     }
     float* final_dst = last ? (next_pad ? next_pad : cur) + (size_t)nctx * C : nullptr;
     if (last) *pad_out = next_pad ? next_pad : cur;
+    if (T == 1 && row_hist && items && n_items && j < VV_ROW_BLOCKS && B.hist && !B.q_w1.q) {
+      // the one-row stage (C = 2048): mixer + RMSNorm + first GEMM + GELU as one launch (vv_convffn.hip), then the weight-streaming GEMV
+      float* hn = row_hist + (size_t)j * 6 * C;
+      const int one = vv_launch_ffn_in_row(B, net->wdt, cur, other, hid, hn, C, net->eps, (hipStream_t)stream);
+      if (one < 0) return one;
+      if (one) {
+        items[(*n_items)++] = vv_conv_ctx_item{hn, B.hist, 6, 0, C};
+        float* dst1 = (last && final_dst) ? final_dst : other;
+        vv_lin_args a1 = lin_base(hid, 4 * C, 1, B.w2, C, 4 * C, net->wdt, dst1, C);
+        a1.bias = B.b2; a1.gate = B.ffn_gamma; a1.gate_ld = 0; a1.res = other; a1.ldres = C;
+        use_w8(a1, B.q_w2);
+        VV_TRY(vv_linear(&a1, stream));
+        if (dst1 == other) { float* t = cur; cur = other; other = t; }
+        else { cur = nullptr; }
+        continue;
+      }
+    }
     {   // middle stages of a streaming frame (C = 256 / 512): mixer + first GEMM, second GEMM (vv_convffn.hip); the bf16 hidden tile
         // fills the first half of `hid`, the scratch history sits behind it
       float* dst2 = (last && final_dst) ? final_dst : other;
@@ -459,10 +483,12 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
   const bool streaming = convnet_streaming(net);
   size_t poff[VV_MAX_STAGES + 1];
   float* pads = nullptr;
-  vv_conv_ctx_item items[VV_MAX_STAGES + 1];
+  vv_conv_ctx_item items[VV_MAX_STAGES + 1 + VV_ROW_BLOCKS];
   int n_items = 0;
+  float* row_hist = nullptr;
   if (streaming) {
     pads = cvr.take(convnet_pad_floats(net, T0, poff));
+    row_hist = cvr.take(VV_ROW_HIST_FLOATS);
     int64_t Ti = T0;
     for (int i = 0; i <= net->n_stages; ++i) {
       const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
@@ -500,7 +526,7 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
       // the last block writes straight into the next conv's padded input; which buffer that is depends on block parity:
       // block j reads cur -> writes other, then they swap.  The last block's mixer output sits in `other_last`, its
       // result may go anywhere except that buffer and hid: use the buffer holding the (dead) input of that block.
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad));
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad, row_hist, items, &n_items));
     } else {
       float* dstb = next_pad ? next_pad : other;
       hipError_t e = hipMemcpyAsync(dstb + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
@@ -538,10 +564,12 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
   }
   size_t poff[VV_MAX_STAGES + 1];
   float* pads = nullptr;
-  vv_conv_ctx_item items[VV_MAX_STAGES + 1];
+  vv_conv_ctx_item items[VV_MAX_STAGES + 1 + VV_ROW_BLOCKS];
   int n_items = 0;
+  float* row_hist = nullptr;
   if (streaming) {
     pads = cvr.take(convnet_pad_floats(net, T0, poff));
+    row_hist = cvr.take(VV_ROW_HIST_FLOATS);
     int64_t Ti = T0;
     for (int i = 0; i <= net->n_stages; ++i) {
       const vv_conv& cv = (i == net->n_stages) ? net->head : net->sample[i];
@@ -598,7 +626,7 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
     const int nctx = conv_ctx_of(nxt);
     float* next_pad = streaming ? pads + poff[i + 1] : nullptr;
     if (net->n_blocks[i] > 0) {
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad));
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad, row_hist, items, &n_items));
     } else {
       float* dstb = next_pad ? next_pad : other;
       e = hipMemcpyAsync(dstb + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, s);
