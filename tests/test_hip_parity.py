@@ -251,8 +251,55 @@ def test_block1d_single_launch_vs_torch(lib, C_, T):
     assert l.vv_block1d(C.byref(b), L.VV_BF16, xd.data_ptr(), od.data_ptr(), 8, C_, eps, None) != 0
 
 
+@pytest.mark.parametrize("m,n,k,dual,pro,mod,epi,act", [
+    (2, 4608, 1536, True, 1, True, False, 2), (2, 1536, 4608, False, 0, False, True, 0), (2, 8960, 1536, True, 1, False, False, 2),
+    (2, 1536, 8960, False, 0, False, True, 0), (2, 2048, 1536, False, 1, False, False, 0), (2, 1536, 1536, False, 0, False, True, 0),
+    (1, 8192, 2048, False, 1, False, False, 1), (1, 2048, 8192, False, 0, False, True, 0), (4, 4608, 1536, True, 1, True, False, 2),
+    (3, 1536, 4608, False, 0, False, True, 0), (2, 10752, 3584, True, 1, True, False, 2), (2, 3584, 3584, False, 1, False, False, 0),
+    (1, 64, 1536, False, 1, True, False, 0), (2, 132, 1536, False, 0, False, False, 0)])
+def test_matrix_core_gemv_vs_torch(lib, m, n, k, dual, pro, mod, epi, act):
+    """vv_linear at the decode shapes (1..4 rows, bf16 weights) - now on v_mfma_f32_4x4x4_16b_bf16 with hi/lo-split activations
+    (vv_gemv_mfma.hip) - against torch fp32 on the bf16-rounded weights: RMSNorm / adaLN-modulate prologues, bias, GELU, SwiGLU, per-row
+    gate and residual epilogues, K split over waves (k > 2048) and whole-row waves."""
+    L = lib
+    l = L.load()
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    x = r(m, k)
+    w = (r(n, k) / k ** 0.5).bfloat16()
+    w2 = (r(n, k) / k ** 0.5).bfloat16()
+    nw, sh, sc = 1 + r(k, sc=0.1), r(m, k, sc=0.2), r(m, k, sc=0.2)
+    bias, gate, res = r(n, sc=0.1), r(m, n, sc=0.5), r(m, n)
+    d = [t.cuda().contiguous() for t in (x, w, w2, nw, sh, sc, bias, gate, res)]
+    out = torch.full((m, n), float("nan"), device="cuda")
+    a = L.LinArgs()
+    a.x, a.ldx, a.m, a.n, a.k, a.wdt, a.out, a.ldo = d[0].data_ptr(), k, m, n, k, L.VV_BF16, out.data_ptr(), n
+    a.w = d[1].data_ptr()
+    xp = x
+    if pro == 1:
+        a.pro, a.norm_w, a.eps = 1, d[3].data_ptr(), 1e-5
+        xp = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * nw
+        if mod:
+            a.mod_shift, a.mod_scale, a.ld_mod = d[4].data_ptr(), d[5].data_ptr(), k
+            xp = xp * (1 + sc) + sh
+    y = xp.double() @ w.double().T
+    if dual:
+        a.w2, a.act = d[2].data_ptr(), 2
+        y = torch.nn.functional.silu(y) * (xp.double() @ w2.double().T)
+    elif act == 1:
+        a.bias, a.act = d[6].data_ptr(), 1
+        y = torch.nn.functional.gelu(y + bias.double())
+    if epi:
+        a.gate, a.gate_ld, a.res, a.ldres = d[7].data_ptr(), n, d[8].data_ptr(), n
+        y = y * gate.double() + res.double()
+    L.check(l.vv_linear(C.byref(a), None), "vv_linear")
+    torch.cuda.synchronize()
+    e = rel_rms(out.cpu().numpy(), y.float().numpy())
+    assert e < 2e-5, f"m={m} n={n} k={k} dual={dual} pro={pro} mod={mod} epi={epi} act={act}: rel RMS {e:.3e}"
+
+
 @pytest.mark.parametrize("m,n,k,ldx", [(40, 512, 2560, 1280), (200, 256, 1024, 512), (40, 1280, 1024, 1024), (200, 512, 512, 512), (8, 2560, 2048, 2048),
-                                       (37, 48, 2560, 2564), (5, 16, 512, 512), (256, 1024, 1024, 1028)])
+                                       (37, 48, 2560, 2564), (5, 16, 512, 512), (256, 1024, 1024, 1028), (8, 1024, 5120, 2560)])
 def test_resampling_conv_skinny_gemm_vs_torch(lib, m, n, k, ldx):
     """vv_linear at the shapes of a streaming frame's resampling convs (fp32 rows with overlapping windows: ldx < k for a strided conv,
     bf16 weights, bias, no activation): the LDS-free skinny kernel of vv_convffn.hip against torch on the bf16-rounded operands."""

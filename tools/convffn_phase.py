@@ -53,5 +53,41 @@ def run():
         print(f"C={C_} T={T} tile {rows}: " + "  ".join(f"{nm} {v:6.0f} ns" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us", flush=True)
 
 
+def run_narrow():
+    import torch
+    sys.path.insert(0, ROOT)
+    from vibevoice_rocm_amd import _lib as L
+    lib = C.CDLL(SO)
+    assert lib.vv_init() == 0
+    for C_, T in ((128, 800), (64, 1600), (32, 3200)):
+        g = torch.Generator().manual_seed(1)
+        r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+        p = dict(gamma=r(C_, sc=0.5), ffn_gamma=r(C_, sc=0.5), norm_w=1 + r(C_, sc=0.1), ffn_norm_w=1 + r(C_, sc=0.1), dw_w=r(C_, 7, sc=0.3), dw_b=r(C_, sc=0.1),
+                 w1=(r(4 * C_, C_) / C_ ** 0.5).bfloat16(), b1=r(4 * C_, sc=0.1), w2=(r(C_, 4 * C_) / (4 * C_) ** 0.5).bfloat16(), b2=r(C_, sc=0.1))
+        hist = torch.zeros(6, C_, device="cuda")
+        b = L.Block()
+        for k, v in p.items():
+            setattr(b, k, v.data_ptr())
+        b.hist = hist.data_ptr()
+        x, o = r(T, C_), torch.empty(T, C_, device="cuda")
+        t = (C.c_ulonglong * 8)()
+        call = lambda: lib.vv_block1d(C.byref(b), L.VV_BF16, C.c_void_p(x.data_ptr()), C.c_void_p(o.data_ptr()), T, C_, C.c_float(1e-5), None)
+        for _ in range(5):
+            assert call() == 0
+        torch.cuda.synchronize()
+        lib.vv_block1d_debug_times(t, 1)
+        n = 200
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        lib.vv_block1d_debug_times(t, 1)
+        names = ["loads", "stat+xn", "mixer+norm2", "gemm1+gelu", "gemm2+epi"]
+        ns = [t[i] * 10.0 / n for i in range(5)]
+        print(f"block1d C={C_} T={T}: " + "  ".join(f"{nm} {v:6.0f} ns" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us", flush=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["narrow"]:
+        run_narrow()
+        sys.exit(0)
     (build if sys.argv[1:] == ["build"] else run)()

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 # VV_WITH_CHAIN=1 also builds the experimental persistent chained head kernel (vv_chain.hip: spin-wait grid barriers, needs the GPU
 # to itself; a measured dead end kept for the record).  The product library is built without it.
 WITH_CHAIN = os.environ.get("VV_WITH_CHAIN", "0") == "1"
-SRC = [os.path.join(HERE, "csrc", f) for f in ("vv_kernels.hip", "vv_gemv_stream.hip", "vv_mfma_gemm.hip", "vv_block1d.hip", "vv_convffn.hip", "vv_fused.hip", "vv_attn_decode.hip", "vv_attn_prefill.hip", "vv_model.hip")
+SRC = [os.path.join(HERE, "csrc", f) for f in ("vv_kernels.hip", "vv_gemv_stream.hip", "vv_gemv_mfma.hip", "vv_mfma_gemm.hip", "vv_block1d.hip", "vv_convffn.hip", "vv_fused.hip", "vv_attn_decode.hip", "vv_attn_prefill.hip", "vv_model.hip")
        if os.path.exists(os.path.join(HERE, "csrc", f))]
 if WITH_CHAIN:
     SRC.append(os.path.join(HERE, "csrc", "vv_chain.hip"))

@@ -68,13 +68,25 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   const float2* rp = rope + (int64_t)r * half + (lo ? e0 : pe0);
   const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 2);
   const float4 r2 = *reinterpret_cast<const float4*>(rp + 4), r3 = *reinterpret_cast<const float4*>(rp + 6);
-  const int pos = lens[r];
   const int64_t base = ((((int64_t)layer * kv.rows + r) * kv.kv_heads + kvh) * kv.s_max) * d;
   bf16_t* kc = reinterpret_cast<bf16_t*>(kv.k) + base;
   bf16_t* vc = reinterpret_cast<bf16_t*>(kv.v) + base;
+  att_raw kraw[2][ATT_UNR], vraw[2][ATT_UNR];
+  // Unsplit contexts (the common case): the first batch of keys is requested together with q / k / v / rope, BEFORE the position is
+  // known - slots past the position are masked (and their values zeroed: the cache behind the position may hold anything) when the
+  // batch is consumed.  Waiting for lens[r] first put one more memory round trip in front of every layer's attention.
+  const bool spec = nsplit == 1;
+  if (spec) {
+#pragma unroll
+    for (int u = 0; u < ATT_UNR; ++u) {
+      const int sc = min(grp + u * NG, kv.s_max - 1);
+      kraw[0][u] = *reinterpret_cast<const att_raw*>(kc + (int64_t)sc * d + e0);
+      vraw[0][u] = *reinterpret_cast<const att_raw*>(vc + (int64_t)sc * d + e0);
+    }
+  }
+  const int pos = lens[r];
   const int per = (pos + nsplit - 1) / nsplit;              // this block's keys [ks, ke) of the pos cached ones
   const int ks = split * per, ke = min(pos, ks + per);
-  att_raw kraw[2][ATT_UNR], vraw[2][ATT_UNR];
   auto issue_kv = [&](int buf, int s0) {
 #pragma unroll
     for (int u = 0; u < ATT_UNR; ++u) {
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
     }
   };
   const int s_first = ks + grp;
-  if (s_first < ke) issue_kv(0, s_first);
+  if (!spec && s_first < ke) issue_kv(0, s_first);
   const float qsc = rsqrtf((float)d) * 1.4426950408889634f;  // scores in the log2 domain
   const float cs[8] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z}, sn[8] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
   const float qa[8] = {qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w}, qb[8] = {qb0.x, qb0.y, qb0.z, qb0.w, qb1.x, qb1.y, qb1.z, qb1.w};
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   float mmax = -INFINITY, lsum = 0.f, acc[EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
-  auto consume = [&](int buf, int s0) {
+  auto consume = [&](int buf, int s0, bool scrub) {
     float dot[ATT_UNR], vx[ATT_UNR][EPL];
     float bm = -INFINITY;
 #pragma unroll
@@ -108,11 +120,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
       float kx[EPL];
       unpack8(kraw[buf][u], kx);
       unpack8(vraw[buf][u], vx[u]);
+      const bool live = s0 + u * NG < ke;
+      if (scrub && !live) {                          // a slot read ahead of the position: whatever bits it holds must not reach 0 * v
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) vx[u][j] = 0.f;
+      }
       float dd = 0.f;
 #pragma unroll
       for (int j = 0; j < EPL; ++j) dd = fmaf(q[j], kx[j], dd);
       dd = gsum16(dd);
-      dot[u] = (s0 + u * NG < ke) ? dd : -INFINITY;
+      dot[u] = live ? dd : -INFINITY;
       bm = fmaxf(bm, dot[u]);
     }
     if (bm == -INFINITY) return;                 // uniform over the lane group: no key in this batch
@@ -134,10 +151,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   const int stride = NG * ATT_UNR;
   for (int s0 = s_first; s0 < ke; s0 += 2 * stride) {       // two batches in flight, buffers with fixed roles
     if (s0 + stride < ke) issue_kv(1, s0 + stride);
-    consume(0, s0);
+    consume(0, s0, spec && s0 == s_first);
     if (s0 + stride >= ke) break;
     if (s0 + 2 * stride < ke) issue_kv(0, s0 + 2 * stride);
-    consume(1, s0 + stride);
+    consume(1, s0 + stride, false);
   }
   if (split == 0 && grp == 0) {
     // the new token itself, straight from the projection (its cache slot may not be written yet by the block that owns it)

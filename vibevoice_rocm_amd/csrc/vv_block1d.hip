@@ -24,6 +24,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// phase timing of workgroup 0 / thread 0, debug builds only (-DVV_CF_TIMING, tools/convffn_phase.py)
+#ifdef VV_CF_TIMING
+__device__ unsigned long long g_b1_t[8];
+#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); g_b1_t[i] += (unsigned long long)(t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+
 constexpr int TR = 32;          // rows per workgroup (one MFMA tile)
 constexpr int HALO = 6;         // causal depthwise kernel 7
 
@@ -65,6 +73,9 @@ template <int C> struct Lay {
 template <int C>
 __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ x, float* __restrict__ out, int T, const vv_block B, float eps) {
   using L = Lay<C>;
+#ifdef VV_CF_TIMING
+  long long tprev_ = wall_clock64();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* xn = reinterpret_cast<float*>(smem);                                    // [TR + 6][C] normalised window
   float* x1s = reinterpret_cast<float*>(smem + L::XN);                           // [TR][C] mixer output (fp32: residual of the FFN)
@@ -77,8 +88,40 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   const int cq = tid % L::F4, rloc = tid / L::F4;
   const int c0 = cq * 4;
 
-  // The weights do not depend on the activations: this wave's W1 fragments (C/32 blocks x C/16 steps x 16 B per lane, <= 128
-  // VGPRs) are requested before anything else so their L2 latency hides behind the mixer.
+  // ---- 1. window rows t0-6 .. t0+rows-1: raw values stay in registers, normalised values go to LDS -----------------------
+  // Every load of the kernel is requested here, in the order the phases need them: loads return in order, so the window comes first
+  // (with the weights first it sat behind 256 KB of them: 7.4 us before the first statistic at C = 128), then the per-channel
+  // parameters of the mixer, then this wave's W1 fragments (C/32 blocks x C/16 steps x 16 B per lane, <= 128 VGPRs), W2 fragments
+  // (<= 128 VGPRs) and the second GEMM's epilogue operands.  The later phases find their operands in registers instead of starting
+  // another trip to L2 each.
+  float4 own[L::NI];
+  float ss[L::NI];
+#pragma unroll
+  for (int i = 0; i < L::NI; ++i) {
+    const int w = rloc + L::RP * i, t = t0 - HALO + w;
+    own[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w < rows + HALO) {
+      if (t >= 0) own[i] = *reinterpret_cast<const float4*>(x + (int64_t)t * C + c0);
+      else if (B.hist) own[i] = *reinterpret_cast<const float4*>(B.hist + (int64_t)(HALO + t) * C + c0);   // already normalised
+    }
+  }
+  const float4 nw = *reinterpret_cast<const float4*>(B.norm_w + c0);
+  float tap[4][7];
+  {
+    float tq[28];                                                  // 28 consecutive floats: taps of channels c0 .. c0 + 3
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(B.dw_w + (size_t)c0 * 7 + 4 * q);
+      tq[4 * q] = v.x; tq[4 * q + 1] = v.y; tq[4 * q + 2] = v.z; tq[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) tap[c][k] = tq[7 * c + k];
+  }
+  const float4 db = *reinterpret_cast<const float4*>(B.dw_b + c0);
+  const float4 gm = *reinterpret_cast<const float4*>(B.gamma + c0);
+  const float4 fw = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0);
   const int hk = (lane >> 5) * 8;                                  // k offset of this lane inside a 16-wide MFMA step
   const int lm = lane & 31;
   constexpr int NBW = C / 32;                                      // W1 output blocks per wave
@@ -93,10 +136,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
       for (int s = 0; s < ST1; ++s) w1f[j][s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
     }
   }
-
-  // second GEMM: C/32 output blocks, K = 4C split over 4 / (C/32) waves.  All of this wave's W2 fragments (<= 128 VGPRs) and every
-  // per-channel parameter of the kernel are requested here too: nothing but the window load below sits on the critical path, the
-  // later phases find their operands in registers instead of starting another trip to L2 each.
+  // second GEMM: C/32 output blocks, K = 4C split over 4 / (C/32) waves
   constexpr int ST2 = (4 * C / 16) / L::KS;                        // MFMA steps of this wave in the second GEMM
   const int nblk = wave % L::NB2, kpart = wave / L::NB2;
   u32x4 w2f[ST2];
@@ -105,19 +145,6 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < ST2; ++i) w2f[i] = *reinterpret_cast<const u32x4*>(w2r + i * 16);
   }
-
-  // ---- 1. window rows t0-6 .. t0+rows-1: raw values stay in registers, normalised values go to LDS -----------------------
-  float4 own[L::NI];
-  float ss[L::NI];
-  const float4 nw = *reinterpret_cast<const float4*>(B.norm_w + c0);
-  float tap[4][7];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int k = 0; k < 7; ++k) tap[c][k] = B.dw_w[(c0 + c) * 7 + k];
-  const float4 db = *reinterpret_cast<const float4*>(B.dw_b + c0);
-  const float4 gm = *reinterpret_cast<const float4*>(B.gamma + c0);
-  const float4 fw = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0);
   float4 b2v[4], fgv[4];                                           // epilogue of the second GEMM (channel runs of this lane)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -125,16 +152,10 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     b2v[g] = *reinterpret_cast<const float4*>(B.b2 + n);
     fgv[g] = *reinterpret_cast<const float4*>(B.ffn_gamma + n);
   }
+  __builtin_amdgcn_sched_barrier(0);                               // nothing below is scheduled in front of these requests
 #pragma unroll
-  for (int i = 0; i < L::NI; ++i) {
-    const int w = rloc + L::RP * i, t = t0 - HALO + w;
-    own[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (w < rows + HALO) {
-      if (t >= 0) own[i] = *reinterpret_cast<const float4*>(x + (int64_t)t * C + c0);
-      else if (B.hist) own[i] = *reinterpret_cast<const float4*>(B.hist + (int64_t)(HALO + t) * C + c0);   // already normalised
-    }
-    ss[i] = own[i].x * own[i].x + own[i].y * own[i].y + own[i].z * own[i].z + own[i].w * own[i].w;
-  }
+  for (int i = 0; i < L::NI; ++i) ss[i] = own[i].x * own[i].x + own[i].y * own[i].y + own[i].z * own[i].z + own[i].w * own[i].w;
+  BSTAMP(0);                                       // load issue + arrival of the window
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) ss[i] = group_sum<L::F4>(ss[i]);
 #pragma unroll
@@ -150,6 +171,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
+  BSTAMP(1);                                       // statistics + normalised window
 
   // ---- 2. mixer + FFN RMSNorm: x1 = x + gamma (dwconv7(xn) + b); xh = bf16(x1 rstd ffn_norm_w) ----------------------------
   // first GEMM's bias runs: requested now, they arrive while the mixer computes
@@ -192,6 +214,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
+  BSTAMP(2);                                       // mixer + second norm
 
   // ---- 3. hidden = gelu(W1 xh + b1): 4C/32 output blocks, C/32 per wave; K = C ----------------------------------------------
   {
@@ -219,6 +242,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
+  BSTAMP(3);                                       // first GEMM + GELU
 
   // ---- 4. y = W2 hidden + b2; out = x1 + ffn_gamma y -----------------------------------------------------------------------------
   {
@@ -260,6 +284,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
     }
   }
 
+  BSTAMP(4);                                       // second GEMM + epilogue
   // ---- 5. streaming state: the last 6 normalised input rows (T >= 6) --------------------------------------------------------
   if (B.hist && blockIdx.x == 0) {
     for (int j = wave; j < HALO; j += 4) {
@@ -288,6 +313,13 @@ int g_fused = 1;
 
 }  // namespace
 
+#ifdef VV_CF_TIMING
+extern "C" int vv_block1d_debug_times(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_b1_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_b1_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 void vv_block1d_set_fused(int on) { g_fused = on; }
 
 int vv_block1d_init() {
@@ -310,7 +342,7 @@ int vv_launch_block1d(const vv_block& B, int wdt, const float* x, float* out, in
   if (C != 32 && C != 64 && C != 128) return 0;
   auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
   if (!a16(B.w1) || !a16(B.w2) || !a16(B.b1) || !a16(B.b2) || !a16(B.gamma) || !a16(B.ffn_gamma) || !a16(B.norm_w) || !a16(B.ffn_norm_w) ||
-      !a16(B.dw_b) || !B.dw_w || !a16(x) || !a16(out) || (B.hist && !a16(B.hist)))
+      !a16(B.dw_b) || !a16(B.dw_w) || !a16(x) || !a16(out) || (B.hist && !a16(B.hist)))
     return 0;
   if (C == 32) return launch_c<32>(x, out, T, B, eps, s);
   if (C == 64) return launch_c<64>(x, out, T, B, eps, s);

@@ -92,13 +92,7 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
   const int rows = min(TR, T - t0);
   const int lm = lane & 31, hk = (lane >> 5) * 8;
 
-  // ---- everything this workgroup needs from memory, in one burst -------------------------------------------------------------
-  u32x4 wf[L::ST];
-  {
-    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w1) + (int64_t)(n0 + lm) * C + wave * (C / 4) + hk;
-#pragma unroll
-    for (int s = 0; s < L::ST; ++s) wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
-  }
+  // ---- everything this workgroup needs from memory, in one burst, in the order the phases need it (loads return in order) -------
   const int rloc = wave / L::WPR, slot = wave % L::WPR;            // TPR >= 64: a wave sits inside one window row
   int c0[CPT];
 #pragma unroll
@@ -129,8 +123,15 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
       tap[j][4 * q] = tq.x; tap[j][4 * q + 1] = tq.y; tap[j][4 * q + 2] = tq.z; tap[j][4 * q + 3] = tq.w;
     }
   }
+  u32x4 wf[L::ST];
+  {
+    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w1) + (int64_t)(n0 + lm) * C + wave * (C / 4) + hk;
+#pragma unroll
+    for (int s = 0; s < L::ST; ++s) wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
+  }
   const int eg = wave;                                             // epilogue: this thread finishes channels n0 + 8 eg + 4 (lane >> 5) + {0..3}
   const float4 b1v = *reinterpret_cast<const float4*>(B.b1 + n0 + 8 * eg + 4 * (lane >> 5));
+  __builtin_amdgcn_sched_barrier(0);                               // nothing below is scheduled in front of these requests
 
   CSTAMP(0);                                       // address arithmetic + load issue
   // ---- 1. RMS statistic of the window rows ------------------------------------------------------------------------------------
@@ -330,33 +331,37 @@ __global__ __launch_bounds__(64 * NW) void ffn_out_kernel(const bf16_t* __restri
 // (43 us for the 256 -> 512 stride-5 conv: 32 workgroups walking K = 2560).  Here a workgroup owns 16 rows x 16 channels on
 // mfma_f32_16x16x32_bf16, K split over its 4 waves; a lane's B fragment is 8 consecutive floats of its row, converted in registers -
 // no LDS image, no barrier before the MFMAs, every load of the kernel requested up front.
-template <int NST>
+template <int NST, int NB>
 __global__ __launch_bounds__(256) void skinny_kernel(const float* __restrict__ x, int64_t ldx, int M, const bf16_t* __restrict__ W, int K,
                                                      const float* __restrict__ bias, float* __restrict__ out, int64_t ldo) {
+  // K = 4 waves x NB batches x NST steps of 32; a batch is one burst of loads (NB = 2 for K = 5120: 240 registers per burst)
   __shared__ float red[4 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 16, t0 = blockIdx.y * 16;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int kb = wave * (32 * NST) + 8 * kq;
+  const int kb = wave * (32 * NST * NB) + 8 * kq;
   const bf16_t* wr = W + (int64_t)(n0 + r16) * K + kb;
   const float* xr = x + (int64_t)min(t0 + r16, M - 1) * ldx + kb;
-  u32x4 wf[NST];
-  float4 xa[NST], xb[NST];
-#pragma unroll
-  for (int s = 0; s < NST; ++s) {
-    wf[s] = *reinterpret_cast<const u32x4*>(wr + 32 * s);
-    xa[s] = *reinterpret_cast<const float4*>(xr + 32 * s);
-    xb[s] = *reinterpret_cast<const float4*>(xr + 32 * s + 4);
-  }
   const int ei = tid >> 6, el = tid & 63;
   const int en = n0 + 4 * (el >> 4) + ei, em = t0 + (el & 15);
   const float bv = bias ? bias[en] : 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < NST; ++s) {
-    u32x4 p;
-    p.x = pack2(xa[s].x, xa[s].y); p.y = pack2(xa[s].z, xa[s].w); p.z = pack2(xb[s].x, xb[s].y); p.w = pack2(xb[s].z, xb[s].w);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
+  for (int b = 0; b < NB; ++b) {
+    u32x4 wf[NST];
+    float4 xa[NST], xb[NST];
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      wf[s] = *reinterpret_cast<const u32x4*>(wr + 32 * (b * NST + s));
+      xa[s] = *reinterpret_cast<const float4*>(xr + 32 * (b * NST + s));
+      xb[s] = *reinterpret_cast<const float4*>(xr + 32 * (b * NST + s) + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      u32x4 p;
+      p.x = pack2(xa[s].x, xa[s].y); p.y = pack2(xa[s].z, xa[s].w); p.z = pack2(xb[s].x, xb[s].y); p.w = pack2(xb[s].z, xb[s].w);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, p), acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) red[(wave * 4 + i) * 64 + lane] = acc[i];
@@ -406,12 +411,13 @@ int vv_launch_skinny(const vv_lin_args& a, hipStream_t s) {
   if (a.m < g_skinny_min_m || a.m > g_skinny_max_m || a.n % 16 || a.ldx % 4 || a.ldx == 0 || ((uintptr_t)a.x % 16) || ((uintptr_t)a.w % 16)) return 0;
   dim3 grid(a.n / 16, (a.m + 15) / 16);
   const bf16_t* W = reinterpret_cast<const bf16_t*>(a.w);
-#define VV_SK(NSTV) hipLaunchKernelGGL((skinny_kernel<NSTV>), grid, dim3(256), 0, s, a.x, a.ldx, a.m, W, a.k, a.bias, a.out, a.ldo)
+#define VV_SK(NSTV, NBV) hipLaunchKernelGGL((skinny_kernel<NSTV, NBV>), grid, dim3(256), 0, s, a.x, a.ldx, a.m, W, a.k, a.bias, a.out, a.ldo)
   switch (a.k) {
-    case 512: VV_SK(4); break;
-    case 1024: VV_SK(8); break;
-    case 2048: VV_SK(16); break;
-    case 2560: VV_SK(20); break;
+    case 512: VV_SK(4, 1); break;
+    case 1024: VV_SK(8, 1); break;
+    case 2048: VV_SK(16, 1); break;
+    case 2560: VV_SK(20, 1); break;
+    case 5120: VV_SK(20, 2); break;
     default: return 0;
   }
 #undef VV_SK

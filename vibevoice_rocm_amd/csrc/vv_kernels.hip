@@ -36,6 +36,7 @@ extern "C" int vv_init(void) {
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
   VV_TRY(vv_convffn_init());
+  VV_TRY(vv_gemv_mfma_init());
   VV_TRY(vv_fused_init());
   return vv_chain_init();
 }
@@ -64,6 +65,8 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
+  if (key && !strcmp(key, "gemv_mfma")) { vv_gemv_mfma_set(value, 0); return 0; }
+  if (key && !strcmp(key, "gemv_mfma_cap")) { vv_gemv_mfma_set(1, value); return 0; }
   if (key && !strcmp(key, "convffn_t1")) { vv_convffn_set_t1(value); return 0; }
   if (key && !strcmp(key, "convffn_rows512")) { vv_convffn_set_rows(512, value); return 0; }
   if (key && !strcmp(key, "convffn_rows256")) { vv_convffn_set_rows(256, value); return 0; }
@@ -508,6 +511,7 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
   if (vv_launch_skinny(a, s)) return 0;                          // a few rows x K = 512..2560, plain epilogue: the resampling convs (vv_convffn.hip)
   if (a.m <= 8) {
+    if (a.m <= 4) { const int rc = vv_launch_gemv_mfma(a, s); if (rc < 0) return rc; if (rc) return 0; }   // bf16 weights, 1..4 rows: matrix-core GEMV
     if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
       // 5..8 rows not covered above: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
