@@ -86,7 +86,51 @@ def run_narrow():
         print(f"block1d C={C_} T={T}: " + "  ".join(f"{nm} {v:6.0f} ns" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us", flush=True)
 
 
+def run_gemv():
+    import torch
+    sys.path.insert(0, ROOT)
+    from vibevoice_rocm_amd import _lib as L
+    lib = C.CDLL(SO)
+    assert lib.vv_init() == 0
+    for m, n, k, dual, mod, epi, copies in ((2, 4608, 1536, True, True, False, 4), (2, 1536, 4608, False, False, True, 4), (2, 8960, 1536, True, False, False, 12),
+                                            (2, 1536, 8960, False, False, True, 24)):
+        ws = [((torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16(), (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16()) for _ in range(copies)]
+        x, out = torch.randn(m, k, device="cuda"), torch.empty(m, n, device="cuda")
+        nw, sh, sc = torch.ones(k, device="cuda"), torch.zeros(m, k, device="cuda"), torch.zeros(m, k, device="cuda")
+        gate, res = torch.ones(m, n, device="cuda"), torch.zeros(m, n, device="cuda")
+        args = []
+        for i in range(copies):
+            a = L.LinArgs()
+            a.x, a.ldx, a.m, a.n, a.k, a.wdt, a.out, a.ldo = x.data_ptr(), k, m, n, k, L.VV_BF16, out.data_ptr(), n
+            a.w = ws[i][0].data_ptr()
+            if dual:
+                a.w2, a.act, a.pro, a.norm_w, a.eps = ws[i][1].data_ptr(), 2, 1, nw.data_ptr(), 1e-5
+                if mod:
+                    a.mod_shift, a.mod_scale, a.ld_mod = sh.data_ptr(), sc.data_ptr(), k
+            if epi:
+                a.gate, a.gate_ld, a.res, a.ldres = gate.data_ptr(), n, res.data_ptr(), n
+            if copies == 4:
+                a.flags = L.LIN_W_REUSED
+            args.append(a)
+        t = (C.c_ulonglong * 8)()
+        for i in range(8):
+            assert lib.vv_linear(C.byref(args[i % copies]), None) == 0
+        torch.cuda.synchronize()
+        lib.vv_gemv_mfma_debug_times(t, 1)
+        nrep = 240
+        for i in range(nrep):
+            lib.vv_linear(C.byref(args[i % copies]), None)
+        torch.cuda.synchronize()
+        lib.vv_gemv_mfma_debug_times(t, 1)
+        names = ["issue", "x+stats", "barrier1", "norm+split", "barrier2", "frags", "mfma(+w wait)", "reduce+epi"]
+        ns = [t[i] * 10.0 / nrep for i in range(8)]
+        print(f"gemv m={m} n={n} k={k} dual={int(dual)}: " + "  ".join(f"{nm} {v:5.0f}" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us (block 0)", flush=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["gemv"]:
+        run_gemv()
+        sys.exit(0)
     if sys.argv[1:] == ["narrow"]:
         run_narrow()
         sys.exit(0)

@@ -24,6 +24,7 @@ int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_str
 int vv_launch_gemv_mfma(const vv_lin_args& a, hipStream_t s);     // vv_gemv_mfma.hip: 1..4 rows on v_mfma 4x4x4; 1 launched, 0 not covered
 int vv_gemv_mfma_init();
 void vv_gemv_mfma_set(int on, int cap);
+void vv_gemv_mfma_set_nopro(int on);
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
 int vv_mfma_gemm_init();
 #ifdef VV_WITH_CHAIN   // experimental persistent chained head kernel (vv_chain.hip): spin-wait grid barriers, needs the GPU to itself.

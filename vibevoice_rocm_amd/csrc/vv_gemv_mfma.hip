@@ -51,6 +51,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
   hi.x = h[0] | (h[1] << 16); hi.y = h[2] | (h[3] << 16); hi.z = h[4] | (h[5] << 16); hi.w = h[6] | (h[7] << 16);
   lo.x = l[0] | (l[1] << 16); lo.y = l[2] | (l[3] << 16); lo.z = l[4] | (l[5] << 16); lo.w = l[6] | (l[7] << 16);
 }
+// 4 floats -> 4 bf16 "hi" and the bf16 of the remainders "lo" (two dwords each)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  const unsigned h0 = bf16_rne(v.x), h1 = bf16_rne(v.y), h2 = bf16_rne(v.z), h3 = bf16_rne(v.w);
+  const unsigned l0 = bf16_rne(v.x - __uint_as_float(h0 << 16)), l1 = bf16_rne(v.y - __uint_as_float(h1 << 16));
+  const unsigned l2 = bf16_rne(v.z - __uint_as_float(h2 << 16)), l3 = bf16_rne(v.w - __uint_as_float(h3 << 16));
+  hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
 __device__ __forceinline__ s16x4 lo4(const u32x4 v) { const u32x2 t = {v.x, v.y}; return __builtin_bit_cast(s16x4, t); }
 __device__ __forceinline__ s16x4 hi4(const u32x4 v) { const u32x2 t = {v.z, v.w}; return __builtin_bit_cast(s16x4, t); }
 // sum over the 16 lanes that share (lane & 3): two rotates inside the 16-lane DPP row, then the other three rows
@@ -62,13 +70,38 @@ __device__ __forceinline__ float chunk_sum(float v) {
   return v;
 }
 
+// phase timing of workgroup 0 / thread 0, debug builds only (-DVV_CF_TIMING, tools/convffn_phase.py gemv)
+#ifdef VV_CF_TIMING
+__device__ unsigned long long g_gm_t[8];
+#define GSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); g_gm_t[i] += (unsigned long long)(t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
+// Workgroup barrier for LDS traffic only.  __syncthreads() carries a workgroup-scope fence that also drains every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0)): with the row group's weights requested up front the prologue then only starts once all of them have landed, and
+// the kernel becomes "stream everything, then compute" (7.5 + 3.5 us instead of overlapping the two).  The prologue's barriers only
+// order LDS writes and reads, so they wait for the LDS counter alone; the weight registers are not touched before their own wait.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // KW: waves of the block that split K (1: a wave owns whole row groups; 4: one row group per block iteration)
 // NS: steps (of 128 k) per wave, compile-time bound; MR: activation rows held (2 or 4, >= a.m)
 template <int KW, bool DUAL, int NS, int MR>
-__global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, const int n_groups, const int steps_total) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];        // [MR][K] staged activation rows (rows >= m: never read)
+__global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, const int n_groups, const int steps_arg) {
+  // steps_arg < 0 (tuning experiment "gemv_mfma_nopro", timing only): skip the activation prologue and run on whatever the LDS holds - the
+  // time a consumer would take if its producer handed the activations over already normalised and split
+  const bool nopro = steps_arg < 0;
+  const int steps_total = nopro ? -steps_arg : steps_arg;
+  // staged activation rows, already split: bf16 hi [MR][K] then bf16 lo [MR][K] (every thread converts only the chunks it loaded; each
+  // lane's MFMA fragments are then two 16-byte LDS reads per step, no conversion in the wave's instruction stream)
+  extern __shared__ __attribute__((aligned(16))) unsigned char xs_raw[];
+  bf16_t* xh_s = reinterpret_cast<bf16_t*>(xs_raw);
+  bf16_t* xl_s = xh_s + (size_t)MR * a.k;
   __shared__ float red[4 * 4];
   __shared__ float part[2][4][8][4];                                // KW = 4: [parity][wave][register][q]
+#ifdef VV_CF_TIMING
+  long long tprev_ = wall_clock64();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane & 3, b = lane >> 2;
   const int K = a.k, N = a.n, M = a.m;
@@ -99,34 +132,75 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, con
     }
   };
   // ---- activation rows -> LDS (whole block), the first row group's weights requested behind the activation loads -----------------
-  {
+  if (nopro) {
+    issue(g < n_groups ? g : 0);
+  } else {
     const int K4 = K >> 2;
     const bool rms = a.pro == VV_PRO_RMSNORM;
     constexpr int NCH = (KW * NS + 7) / 8;                         // float4 chunks per thread per row (K <= KW * NS * 128)
-    float4 xv[MR][NCH];
+    // Straight-line requests on always-valid addresses (a chunk past the row reads chunk 0, an absent operand reads x): with a guard
+    // or a select per load the compiler consumed each value right away and the prologue became one memory round trip per chunk.
+    // Norm weight and adaLN shift / scale go out with x, AHEAD of the weights: loads return in order.
+    const bool has_nw = rms && a.norm_w, has_mod = rms && a.mod_scale;
+    const float* nwp = has_nw ? a.norm_w : a.x;
+    const float* scp = has_mod ? a.mod_scale : a.x;
+    const float* shp = has_mod ? a.mod_shift : a.x;
+    const int64_t ldm = has_mod ? a.ld_mod : 0;
+    float4 xv[MR][NCH], nwv[NCH], scv[MR][NCH], shv[MR][NCH];
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = tid + 256 * c;
+      const int kk = ch < K4 ? 4 * ch : 0;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int ch = tid + 256 * c;
-        xv[m][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && ch < K4) xv[m][c] = *reinterpret_cast<const float4*>(a.x + (int64_t)m * a.ldx + 4 * ch);
+      for (int m = 0; m < MR; ++m) xv[m][c] = *reinterpret_cast<const float4*>(a.x + (int64_t)(m < M ? m : 0) * a.ldx + kk);
+      nwv[c] = *reinterpret_cast<const float4*>(nwp + kk);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        scv[m][c] = *reinterpret_cast<const float4*>(scp + (int64_t)(m < M ? m : 0) * ldm + kk);
+        shv[m][c] = *reinterpret_cast<const float4*>(shp + (int64_t)(m < M ? m : 0) * ldm + kk);
       }
-    if (g < n_groups) issue(g);
+    }
+    // Every wave of the block has its activation requests in the CU's memory pipeline before any wave adds weight requests behind them
+    // (one queue per CU: a wave that starts a little later would find its few activation lines behind 24 KB of another wave's weights).
+    asm volatile("s_barrier" ::: "memory");
+    issue(g < n_groups ? g : 0);
+    __builtin_amdgcn_sched_barrier(0);
+#define VV_FENCE4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      VV_FENCE4(nwv[c]);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) { VV_FENCE4(xv[m][c]); VV_FENCE4(scv[m][c]); VV_FENCE4(shv[m][c]); }
+    }
+#undef VV_FENCE4
+    if (!has_nw) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) nwv[c] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    if (!has_mod) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) { scv[m][c] = make_float4(0.f, 0.f, 0.f, 0.f); shv[m][c] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    GSTAMP(0);                                     // requests out
     if (rms) {
       float ss[MR];
 #pragma unroll
       for (int m = 0; m < MR; ++m) {
         float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) s1 += (xv[m][c].x * xv[m][c].x + xv[m][c].y * xv[m][c].y) + (xv[m][c].z * xv[m][c].z + xv[m][c].w * xv[m][c].w);
+        for (int c = 0; c < NCH; ++c)
+          s1 += (tid + 256 * c < K4) ? (xv[m][c].x * xv[m][c].x + xv[m][c].y * xv[m][c].y) + (xv[m][c].z * xv[m][c].z + xv[m][c].w * xv[m][c].w) : 0.f;
         ss[m] = vv_wave_sum(s1);
       }
       if (lane == 0) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) red[wave * 4 + m] = ss[m];
       }
-      __syncthreads();
+      GSTAMP(1);                                   // x landed, statistics
+      lds_barrier();
+      GSTAMP(2);                                   // first barrier (waits for every outstanding load of the block)
 #pragma unroll
       for (int m = 0; m < MR; ++m) {
         if (m >= M) break;
@@ -137,13 +211,13 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, con
           if (ch >= K4) break;
           float4 v = xv[m][c];
           v.x *= rstd; v.y *= rstd; v.z *= rstd; v.w *= rstd;
-          if (a.norm_w) { const float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + 4 * ch); v.x *= w4.x; v.y *= w4.y; v.z *= w4.z; v.w *= w4.w; }
-          if (a.mod_scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(a.mod_scale + (int64_t)m * a.ld_mod + 4 * ch);
-            const float4 sh = *reinterpret_cast<const float4*>(a.mod_shift + (int64_t)m * a.ld_mod + 4 * ch);
-            v.x = v.x * (1.0f + sc.x) + sh.x; v.y = v.y * (1.0f + sc.y) + sh.y; v.z = v.z * (1.0f + sc.z) + sh.z; v.w = v.w * (1.0f + sc.w) + sh.w;
-          }
-          *reinterpret_cast<float4*>(xs + (size_t)m * K + 4 * ch) = v;
+          const float4 w4 = nwv[c], sc = scv[m][c], sh = shv[m][c];
+          v.x = v.x * w4.x * (1.0f + sc.x) + sh.x; v.y = v.y * w4.y * (1.0f + sc.y) + sh.y;
+          v.z = v.z * w4.z * (1.0f + sc.z) + sh.z; v.w = v.w * w4.w * (1.0f + sc.w) + sh.w;
+          uint2 h2, l2;
+          split4(v, h2, l2);
+          *reinterpret_cast<uint2*>(xh_s + (size_t)m * K + 4 * ch) = h2;
+          *reinterpret_cast<uint2*>(xl_s + (size_t)m * K + 4 * ch) = l2;
         }
       }
     } else {
@@ -153,27 +227,32 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, con
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int ch = tid + 256 * c;
-          if (ch < K4) *reinterpret_cast<float4*>(xs + (size_t)m * K + 4 * ch) = xv[m][c];
+          if (ch < K4) {
+            uint2 h2, l2;
+            split4(xv[m][c], h2, l2);
+            *reinterpret_cast<uint2*>(xh_s + (size_t)m * K + 4 * ch) = h2;
+            *reinterpret_cast<uint2*>(xl_s + (size_t)m * K + 4 * ch) = l2;
+          }
         }
       }
     }
-    __syncthreads();
+    GSTAMP(3);                                     // normalise + split + LDS
+    lds_barrier();
   }
+  GSTAMP(4);                                       // second barrier
   // ---- this lane's B fragments: activation row q, chunk b of every step ------------------------------------------------------------
   u32x4 xh[NS], xl[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    float v[8];
+    xh[s] = u32x4{0u, 0u, 0u, 0u};
+    xl[s] = xh[s];
     if (q < M && s < cnt) {
-      const float* p = xs + (size_t)q * K + (size_t)(s0 + s) * 128 + 8 * b;
-      const float4 p0 = *reinterpret_cast<const float4*>(p), p1 = *reinterpret_cast<const float4*>(p + 4);
-      v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      const size_t o = (size_t)q * K + (size_t)(s0 + s) * 128 + 8 * b;
+      xh[s] = *reinterpret_cast<const u32x4*>(xh_s + o);
+      xl[s] = *reinterpret_cast<const u32x4*>(xl_s + o);
     }
-    split8(v, xh[s], xl[s]);
   }
+  GSTAMP(5);                                       // fragments from LDS
   // ---- row groups -------------------------------------------------------------------------------------------------------------------
   int parity = 0;
   while (g < n_groups) {
@@ -200,6 +279,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, con
         acc2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(hi4(wb[s]), hi4(xl[s]), acc2, 0, 0, 0);
       }
     }
+    GSTAMP(6);                                     // MFMAs (incl. the wait for the weights)
     const int gn = g + gstride;
     if (gn < n_groups) issue(gn);                                  // the next group's weights stream in behind the reduction / epilogue
     float v[4], v2[4];
@@ -210,7 +290,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) { part[parity][wave][r][q] = v[r]; part[parity][wave][4 + r][q] = v2[r]; }
       }
-      __syncthreads();                                             // g is block-uniform; partials alternate between two buffers
+      lds_barrier();                                               // g is block-uniform; partials alternate between two buffers
       if (owner) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -233,10 +313,20 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(const vv_lin_args a, con
       *reinterpret_cast<float4*>(a.out + (int64_t)q * a.ldo + n0) = make_float4(o[0], o[1], o[2], o[3]);
     }
     g = gn;
+    GSTAMP(7);                                     // reduction + epilogue
   }
 }
 
-int g_on = 1;
+// OFF by default.  Measured on MI355X against the VALU kernel (tools/mb_chain_lin.py ab gemv_mfma 0,1; us per launch inside a graph chain):
+// head SwiGLU 11.1 vs 9.1, head down 8.0 vs 5.5, LLM SwiGLU 15.3 vs 13.8, LLM down 18.2 vs 9.0, qkv 5.4 vs 5.3, o 4.8 vs 4.0.  With one row
+// group per wave the kernel is "request everything, then compute": the block-wide activation prologue (statistics, normalise, split:
+// ~4.5 us of latency behind the CU's own weight traffic, tools/convffn_phase.py gemv) and the MFMA / reduction tail do not overlap with
+// the stream the way the VALU kernel's steady-state loop does.  Even with the prologue removed (activations handed over already
+// normalised and split - "gemv_mfma_nopro", timing only) it reaches 8.7 / 4.9 / 13.3 / 9.7 / 3.9 / 3.9 us: the upper bound of that
+// redesign is ~150 us per frame, not the 450 us the row-count scaling of the VALU kernel suggested.  Kept for that next step and for
+// batches of dialogues (its cost does not grow with the row count up to 4); vv_tune("gemv_mfma", 1) enables it.
+int g_on = 0;
+int g_nopro = 0;
 int g_cap = 512;      // persistent workgroups (2 per CU)
 
 template <int KW, bool DUAL, int NS>
@@ -244,13 +334,22 @@ void launch(const vv_lin_args& a, hipStream_t s, int steps) {
   const int n_groups = a.n / 4;
   const int work = (KW == 1) ? (n_groups + 3) / 4 : n_groups;
   const int blocks = work < g_cap ? work : g_cap;
+  if (g_nopro) steps = -steps;
   if (a.m <= 2) hipLaunchKernelGGL((gemv_mfma_kernel<KW, DUAL, NS, 2>), dim3(blocks), dim3(256), (size_t)2 * a.k * sizeof(float), s, a, n_groups, steps);
   else hipLaunchKernelGGL((gemv_mfma_kernel<KW, DUAL, NS, 4>), dim3(blocks), dim3(256), (size_t)4 * a.k * sizeof(float), s, a, n_groups, steps);
 }
 
 }  // namespace
 
+#ifdef VV_CF_TIMING
+extern "C" int vv_gemv_mfma_debug_times(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gm_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_gm_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 void vv_gemv_mfma_set(int on, int cap) { g_on = on; if (cap > 0) g_cap = cap; }
+void vv_gemv_mfma_set_nopro(int on) { g_nopro = on; }
 
 int vv_gemv_mfma_init() {     // before any graph capture: the staged rows can exceed the default dynamic LDS limit
 #define VV_GM_ATTR1(KWV, D, NSV, MRV)                                                                                                       \

@@ -66,6 +66,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
   if (key && !strcmp(key, "gemv_mfma")) { vv_gemv_mfma_set(value, 0); return 0; }
+  if (key && !strcmp(key, "gemv_mfma_nopro")) { vv_gemv_mfma_set(1, 0); vv_gemv_mfma_set_nopro(value); return 0; }
   if (key && !strcmp(key, "gemv_mfma_cap")) { vv_gemv_mfma_set(1, value); return 0; }
   if (key && !strcmp(key, "convffn_t1")) { vv_convffn_set_t1(value); return 0; }
   if (key && !strcmp(key, "convffn_rows512")) { vv_convffn_set_rows(512, value); return 0; }
