@@ -45,6 +45,7 @@ __device__ __forceinline__ void unpack8_f8(const u32x4 v, float (&o)[8]) {
 // epilogue operands (bias / adaLN gate / residual) of one output: their addresses are known before the dot product is, so
 // they are loaded one row group ahead, in front of the weight loads that follow them in the queue (loads return in order: an
 // operand load issued at epilogue time would sit behind two row groups of prefetched weights)
+typedef float vf2 __attribute__((ext_vector_type(2)));
 struct EpiOp { float b, g, r, s, s2; };   // bias, gate, residual, fp8 row scales (raw loads; absent operands are ignored at use)
 __device__ __forceinline__ EpiOp epi_load(const vv_lin_args& a, int m, int n) {
   // straight-line and use-free: an absent operand reads x[0] (always a valid address), the values are only looked at in epi_pre.
@@ -411,11 +412,14 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 512 : 64 * KSPLIT) void gemv_stream_k
   int parity = 0;
   while (g < n_groups) {
     const int gn = g + gstride;
-    float acc[RW][M], acc2[DUAL ? RW : 1][M];
+    // The dot products run on packed fp32 FMAs (v_pk_fma_f32: two lanes of a register pair per instruction): even and odd k of a lane
+    // accumulate separately and are added once per row group.  This loop, not the memory system, sets the kernel's pace (its time grows
+    // 1.2-1.6 us per activation row, tools/mb_rows.py); half the FMA instructions per weight load is the cheapest cut.
+    vf2 pacc[RW][M], pacc2[DUAL ? RW : 1][M];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int m = 0; m < M; ++m) { acc[r][m] = 0.f; if (DUAL) acc2[r][m] = 0.f; }
+      for (int m = 0; m < M; ++m) { pacc[r][m] = vf2{0.f, 0.f}; if (DUAL) pacc2[r][m] = vf2{0.f, 0.f}; }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
 #pragma unroll
@@ -426,17 +430,22 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 512 : 64 * KSPLIT) void gemv_stream_k
 #pragma unroll
         for (int m = 0; m < M; ++m) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            acc[r][m] = fmaf(w[j], xr[m][u][j], acc[r][m]);
-            if (DUAL) acc2[r][m] = fmaf(w2[j], xr[m][u][j], acc2[r][m]);
+          for (int j = 0; j < 8; j += 2) {
+            const vf2 xp = {xr[m][u][j], xr[m][u][j + 1]};
+            pacc[r][m] = __builtin_elementwise_fma(vf2{w[j], w[j + 1]}, xp, pacc[r][m]);
+            if (DUAL) pacc2[r][m] = __builtin_elementwise_fma(vf2{w2[j], w2[j + 1]}, xp, pacc2[r][m]);
           }
         }
       }
     }
+    float acc[RW][M], acc2[DUAL ? RW : 1][M];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-      for (int m = 0; m < M; ++m) { acc[r][m] = wsum(acc[r][m]); if (DUAL) acc2[r][m] = wsum(acc2[r][m]); }
+      for (int m = 0; m < M; ++m) {
+        acc[r][m] = wsum(pacc[r][m].x + pacc[r][m].y);
+        if (DUAL) acc2[r][m] = wsum(pacc2[r][m].x + pacc2[r][m].y);
+      }
     if (KSPLIT == 1) {
       if (lane < RW * M) {                         // every lane holds all sums: lane r * M + m keeps (r, m)
         float v = acc[0][0], v2 = DUAL ? acc2[0][0] : 0.f;
