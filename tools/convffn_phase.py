@@ -127,7 +127,46 @@ def run_gemv():
         print(f"gemv m={m} n={n} k={k} dual={int(dual)}: " + "  ".join(f"{nm} {v:5.0f}" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us (block 0)", flush=True)
 
 
+def run_attn():
+    import torch
+    sys.path.insert(0, ROOT)
+    from vibevoice_rocm_amd import _lib as L
+    lib = C.CDLL(SO)
+    assert lib.vv_init() == 0
+    heads, kvh, d, layers, R = 12, 2, 128, 4, 2
+    for S in (450, 900):
+        s_max = 1024
+        k = torch.randn(layers, R, kvh, s_max, d, device="cuda").bfloat16()
+        v = torch.randn(layers, R, kvh, s_max, d, device="cuda").bfloat16()
+        kv = L.KV()
+        kv.k, kv.v, kv.layers, kv.rows, kv.kv_heads, kv.s_max, kv.head_dim, kv.kvdt = k.data_ptr(), v.data_ptr(), layers, R, kvh, s_max, d, L.VV_BF16
+        qkv = torch.randn(R, (heads + 2 * kvh) * d, device="cuda")
+        lens = torch.tensor([S, S // 4], dtype=torch.int32, device="cuda")
+        inv = (1.0 / (1e6 ** (torch.arange(0, d, 2).float() / d))).cuda()
+        rope = torch.empty(R * d, device="cuda")
+        out = torch.empty(R, heads * d, device="cuda")
+        assert lib.vv_rope_table(C.c_void_p(lens.data_ptr()), C.c_void_p(inv.data_ptr()), R, d, C.c_void_p(rope.data_ptr()), None) == 0
+        t = (C.c_ulonglong * 8)()
+        call = lambda l: lib.vv_attn_decode(C.c_void_p(qkv.data_ptr()), C.c_int64(qkv.shape[1]), R, heads, C.byref(kv), l, C.c_void_p(rope.data_ptr()),
+                                            C.c_void_p(lens.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int64(heads * d), None)
+        for i in range(8):
+            assert call(i % layers) == 0, lib.vv_last_error()
+        torch.cuda.synchronize()
+        lib.vv_attn_debug_times(t, 1)
+        n = 200
+        for i in range(n):
+            call(i % layers)
+        torch.cuda.synchronize()
+        lib.vv_attn_debug_times(t, 1)
+        names = ["issue+pos", "q/k/rope", "key batches", "new token", "merge+store"]
+        ns = [t[i] * 10.0 / n for i in range(5)]
+        print(f"attn S={S}: " + "  ".join(f"{nm} {v:5.0f}" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us (block 0)", flush=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["attn"]:
+        run_attn()
+        sys.exit(0)
     if sys.argv[1:] == ["gemv"]:
         run_gemv()
         sys.exit(0)

@@ -41,6 +41,13 @@ __device__ __forceinline__ unsigned bf16_bits(float f) {   // round to nearest e
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// phase timing of block (0,0,0) / thread 0, debug builds only (-DVV_CF_TIMING, tools/convffn_phase.py attn)
+#ifdef VV_CF_TIMING
+__device__ unsigned long long g_at_t[8];
+#define ASTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { const long long t_ = wall_clock64(); g_at_t[i] += (unsigned long long)(t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
 #define ATT_UNR 4
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer, const float2* rope, const int* lens,
@@ -49,6 +56,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   __shared__ __attribute__((aligned(16))) float sacc[NG][d];
   __shared__ float sm_[NG], sl_[NG];
   __shared__ int s_last;
+#ifdef VV_CF_TIMING
+  long long tprev_ = wall_clock64();
+#endif
   const int r = blockIdx.y, h = blockIdx.x, split = blockIdx.z, nsplit = gridDim.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gl = lane & 15, gi = lane >> 4, grp = wave * 4 + gi;
@@ -98,6 +108,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   };
   const int s_first = ks + grp;
   if (!spec && s_first < ke) issue_kv(0, s_first);
+  ASTAMP(0);                                       // requests out, position known
   const float qsc = rsqrtf((float)d) * 1.4426950408889634f;  // scores in the log2 domain
   const float cs[8] = {r0.x, r0.z, r1.x, r1.z, r2.x, r2.z, r3.x, r3.z}, sn[8] = {r0.y, r0.w, r1.y, r1.w, r2.y, r2.w, r3.y, r3.w};
   const float qa[8] = {qa0.x, qa0.y, qa0.z, qa0.w, qa1.x, qa1.y, qa1.z, qa1.w}, qb[8] = {qb0.x, qb0.y, qb0.z, qb0.w, qb1.x, qb1.y, qb1.z, qb1.w};
@@ -109,6 +120,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
     q[j] = (lo ? qa[j] * cs[j] - qb[j] * sn[j] : qa[j] * cs[j] + qb[j] * sn[j]) * qsc;
     kn[j] = lo ? ka[j] * cs[j] - kb[j] * sn[j] : ka[j] * cs[j] + kb[j] * sn[j];
   }
+  ASTAMP(1);                                       // q / k / rope landed, RoPE
   float mmax = -INFINITY, lsum = 0.f, acc[EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
     if (s0 + 2 * stride < ke) issue_kv(0, s0 + 2 * stride);
     consume(1, s0 + stride, false);
   }
+  ASTAMP(2);                                       // key batches
   if (split == 0 && grp == 0) {
     // the new token itself, straight from the projection (its cache slot may not be written yet by the block that owns it)
     float dd = 0.f;
@@ -177,6 +190,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
       *reinterpret_cast<att_raw*>(vc + (int64_t)pos * d + e0) = pv;
     }
   }
+  ASTAMP(3);                                       // new token + append
   // every lane group's (m, l, acc[128]) to LDS, then each output thread folds them itself: one barrier
   if (gl == 0) { sm_[grp] = mmax; sl_[grp] = lsum; }
   *reinterpret_cast<float4*>(&sacc[grp][e0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   }
   if (nsplit == 1) {
     if (tid < d) out[(int64_t)r * ldo + h * d + tid] = num / den;
+    ASTAMP(4);                                     // merge + store
     return;
   }
   // split keys: partial (M, den, num[128]) per block; the block that draws the last ticket folds them
@@ -247,3 +262,11 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_attn_decode: %s", hipGetErrorString(e));
   return 1;
 }
+
+#ifdef VV_CF_TIMING
+extern "C" int vv_attn_debug_times(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_at_t), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_at_t), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
