@@ -374,3 +374,21 @@ def test_batch_of_six_shares_streams_and_equals_singles(big):
         one = m.generate(input_ids=ids[b][None], tokenizer=tok, cfg_scale=2.0, forced_tokens=forced[b], noise=noise[b])
         assert torch.equal(out.speech_outputs[b], one.speech_outputs[0]), f"sample {b}: batch of 6 differs from its single run"
         assert out.sequences[b, L: L + len(forced[b])].tolist() == forced[b]
+
+
+def test_engine_streams_are_recycled(big):
+    """Engines hand their HIP stream back when they die and new engines take it from the free list: the number of streams a process
+    has ever used stays at the number of engines alive at once (a process with more than ~5 used streams runs concurrent lanes 2-3x
+    slower on MI355X: engine.py, _IDLE_STREAMS)."""
+    import gc
+    from vibevoice_rocm_amd import engine as E
+    cfg, sd, m = big
+    seen = set()
+    for _ in range(4):
+        e = E.Engine(cfg, sd, device="cuda:0", dtype=torch.bfloat16)
+        seen.add(e.stream.cuda_stream)
+        e.stream.synchronize()
+        del e
+        gc.collect()
+    assert len(seen) == 1, f"4 engines in sequence used {len(seen)} different streams"
+    assert any(s.cuda_stream in seen for s in E._IDLE_STREAMS.get("cuda:0", []))

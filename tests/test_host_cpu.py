@@ -280,3 +280,18 @@ def test_sharding_world3_scatter_allgather_gloo():
         p.join(60)
     assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True), (2, True)]
     assert [it for _, _, it in res] == [[0, 3], [1, 4], [2]]
+
+
+def test_hw_queue_default_is_set_on_import():
+    """The package sets GPU_MAX_HW_QUEUES=8 unless the user chose a value (4 lanes + the copy stream oversubscribe the default 4)."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", "import os, vibevoice_rocm_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"], env=env, capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "8", out.stderr[-400:]
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    out = subprocess.run([sys.executable, "-c", "import os, vibevoice_rocm_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"], env=env, capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "4"
