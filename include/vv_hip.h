@@ -261,7 +261,8 @@ typedef struct vv_block {
  * run vv_block_mixer + two vv_linear).  b->hist (or NULL) is the streaming state, updated in place. */
 int vv_block1d(const struct vv_block* b, int wdt, const float* x, float* out, int T, int C, float eps, vv_stream_t stream);
 
-/* The same Block1D for the middle stages of a streaming frame (bf16 weights, C = 256 / 512, 3 <= T <= 256) as two launches (mixer +
+/* The same Block1D for the middle stages of a streaming frame (bf16 weights; C = 256 / 512 with 3 <= T <= 256, C = 1024 with T <= 64,
+ * C = 128 with T <= 1024) as two launches (mixer +
  * first FFN GEMM, second FFN GEMM): x[T, C] -> out[T, C] (out != x).  ws: vv_block_mid_ws_bytes(T, C) bytes of scratch, 16-byte aligned.
  * Other shapes return VV_E_UNSUPPORTED.  b->hist as above. */
 size_t vv_block_mid_ws_bytes(int T, int C);

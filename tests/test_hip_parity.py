@@ -332,7 +332,7 @@ def test_resampling_conv_skinny_gemm_vs_torch(lib, m, n, k, ldx):
     assert e < 1e-5, f"m={m} n={n} k={k} ldx={ldx}: rel RMS {e:.3e}"
 
 
-@pytest.mark.parametrize("C_,T", [(512, 40), (256, 200), (512, 37), (256, 5), (512, 64), (256, 256), (512, 3), (1024, 8), (1024, 13), (1024, 4)])
+@pytest.mark.parametrize("C_,T", [(512, 40), (256, 200), (512, 37), (256, 5), (512, 64), (256, 256), (512, 3), (1024, 8), (1024, 13), (1024, 4), (128, 800), (128, 45), (128, 7)])
 def test_block_mid_two_launches_vs_torch(lib, C_, T):
     """vv_block_mid (middle-stage Block1D of a streaming frame as two launches: mixer + first FFN GEMM, second FFN GEMM; vv_convffn.hip)
     against the torch fp32 restatement of Block1D.forward (modular_vibevoice_tokenizer.py:555-600) on the same bf16-rounded weights:

@@ -75,6 +75,8 @@ void vv_convffn_set(int on);
 int vv_launch_ffn_in_row(const vv_block& B, int wdt, const float* x, float* y, float* hidden, float* hist_new, int C, float eps, hipStream_t s);
 void vv_convffn_set_t1(int on);
 void vv_convffn_set_rows(int c, int rows);
+void vv_convffn_set_c128(int on);
+bool vv_convffn_prefers(int wdt, int T, int C);
 int vv_launch_skinny(const vv_lin_args& a, hipStream_t s);       // resampling convs of a streaming frame: 1 launched, 0 not covered
 void vv_skinny_set(int on, int min_m, int max_m);
 int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int rows, int n, float* out, int64_t ldo, hipStream_t s);

@@ -50,9 +50,11 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 __device__ __forceinline__ float sq4(const float4 v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 
 template <int C, int TRV> struct InLay {                  // TRV: sequence rows per workgroup (<= 32; the MFMA tile stays 32 wide)
-  static constexpr int F4 = C / 4;                        // float4 columns per row
-  static constexpr int TPR = F4 < 256 ? F4 : 256;         // threads per row
-  static constexpr int CPT = F4 / TPR;                    // float4 columns per thread per row (2 at C = 2048)
+  static constexpr int VW = C >= 256 ? 4 : 2;             // floats per thread per column group (C = 128: 64 threads x float2 keep a wave inside one row)
+  static constexpr int F4 = C / 4;                        // float4 columns per row (history copy)
+  static constexpr int FV = C / VW;                       // column groups per row
+  static constexpr int TPR = FV < 256 ? FV : 256;         // threads per row
+  static constexpr int CPT = FV / TPR;                    // column groups per thread per row (2 at C = 2048)
   static constexpr int RP = 256 / TPR;                    // window rows per pass of the 256 threads
   static constexpr int NI = (TRV + HALO + RP - 1) / RP;   // passes over the window (TRV + 6 rows)
   static constexpr int WR = NI * RP;                      // window rows held in LDS (>= TRV + 6: no row guards on the LDS side)
@@ -66,14 +68,22 @@ template <int C, int TRV> struct InLay {                  // TRV: sequence rows 
   static constexpr size_t LDS = (XN > RED ? XN : RED) + XH + PART;
 };
 
-__device__ __forceinline__ float4 mul4(const float4 a, const float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+// VW-wide (4 or 2 floats) loads / stores of a thread's column group
+template <int VW> __device__ __forceinline__ void ldv(const float* p, float (&o)[VW]) {
+  if constexpr (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+  else { const float2 t = *reinterpret_cast<const float2*>(p); o[0] = t.x; o[1] = t.y; }
+}
+template <int VW> __device__ __forceinline__ void stv(float* p, const float (&o)[VW]) {
+  if constexpr (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  else *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]);
+}
 
 // HF32: the hidden tile is written in fp32 (the T = 1 stage, whose second GEMM stays on the weight-streaming GEMV)
 template <int C, int TRV, bool HF32>
 __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, void* __restrict__ hidden_v,
                                                      float* __restrict__ hist_new, int T, const vv_block B, float eps) {
   using L = InLay<C, TRV>;
-  constexpr int TR = TRV, CPT = L::CPT;
+  constexpr int TR = TRV, CPT = L::CPT, VW = L::VW;
 #ifdef VV_CF_TIMING
   long long tprev_ = wall_clock64();
 #endif
@@ -96,10 +106,10 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
   const int rloc = wave / L::WPR, slot = wave % L::WPR;            // TPR >= 64: a wave sits inside one window row
   int c0[CPT];
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) c0[j] = 4 * (tid % L::TPR + L::TPR * j);
+  for (int j = 0; j < CPT; ++j) c0[j] = VW * (tid % L::TPR + L::TPR * j);
   const float* hb = B.hist ? B.hist : x;                           // history rows of a stateless call read x row 0 and are zeroed below
   const float hkeep = B.hist ? 1.f : 0.f;
-  float4 own[L::NI][CPT];
+  float own[L::NI][CPT][VW];
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i, t = t0 - HALO + w;
@@ -107,20 +117,26 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
     const float* src = isx ? x + (int64_t)min(t, T - 1) * C : hb + (int64_t)(B.hist ? HALO + t : 0) * C;
     const float keep = (w < rows + HALO) ? (isx ? 1.f : hkeep) : 0.f;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) own[i][j] = mul4(*reinterpret_cast<const float4*>(src + c0[j]), keep);
+    for (int j = 0; j < CPT; ++j) {
+      ldv<VW>(src + c0[j], own[i][j]);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) own[i][j][e] *= keep;
+    }
   }
-  float4 nw[CPT], db[CPT], gm[CPT], fw[CPT];
-  float tap[CPT][28];                                              // tap[j][7 c + k] of channels c0[j] .. c0[j] + 3
+  float nw[CPT][VW], db[CPT][VW], gm[CPT][VW], fw[CPT][VW];
+  float tap[CPT][VW * 7];                                          // tap[j][7 c + k] of channels c0[j] .. c0[j] + VW - 1
 #pragma unroll
   for (int j = 0; j < CPT; ++j) {
-    nw[j] = *reinterpret_cast<const float4*>(B.norm_w + c0[j]);
-    db[j] = *reinterpret_cast<const float4*>(B.dw_b + c0[j]);
-    gm[j] = *reinterpret_cast<const float4*>(B.gamma + c0[j]);
-    fw[j] = *reinterpret_cast<const float4*>(B.ffn_norm_w + c0[j]);
+    ldv<VW>(B.norm_w + c0[j], nw[j]);
+    ldv<VW>(B.dw_b + c0[j], db[j]);
+    ldv<VW>(B.gamma + c0[j], gm[j]);
+    ldv<VW>(B.ffn_norm_w + c0[j], fw[j]);
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
-      const float4 tq = *reinterpret_cast<const float4*>(B.dw_w + (size_t)c0[j] * 7 + 4 * q);
-      tap[j][4 * q] = tq.x; tap[j][4 * q + 1] = tq.y; tap[j][4 * q + 2] = tq.z; tap[j][4 * q + 3] = tq.w;
+      float tq[VW];
+      ldv<VW>(B.dw_w + (size_t)c0[j] * 7 + VW * q, tq);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) tap[j][VW * q + e] = tq[e];
     }
   }
   u32x4 wf[L::ST];
@@ -138,9 +154,11 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i;
-    float q = sq4(own[i][0]);
+    float q = 0.f;
 #pragma unroll
-    for (int j = 1; j < CPT; ++j) q += sq4(own[i][j]);
+    for (int j = 0; j < CPT; ++j)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) q = fmaf(own[i][j][e], own[i][j][e], q);
     const float s = vv_wave_sum(q);
     if (lane == 0) part[w * 4 + slot] = s;
   }
@@ -156,20 +174,23 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
     const float rstd = isx ? rsqrtf(ss / (float)C + eps) : 1.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-      const float4 ww = isx ? nw[j] : make_float4(1.f, 1.f, 1.f, 1.f);
-      *reinterpret_cast<float4*>(xn + w * C + c0[j]) =
-          make_float4(own[i][j].x * rstd * ww.x, own[i][j].y * rstd * ww.y, own[i][j].z * rstd * ww.z, own[i][j].w * rstd * ww.w);
+      float o[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) o[e] = own[i][j][e] * rstd * (isx ? nw[j][e] : 1.f);
+      stv<VW>(xn + w * C + c0[j], o);
     }
   }
   __syncthreads();
   CSTAMP(2);                                       // normalised window to LDS
 
   // ---- 2. mixer, then the FFN's RMS statistic ------------------------------------------------------------------------------------
-  float4 y1[L::NI][CPT];
+  float y1[L::NI][CPT][VW];
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) y1[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < CPT; ++j)
+#pragma unroll
+      for (int e = 0; e < VW; ++e) y1[i][j][e] = 0.f;
     if (L::RP * i + L::RP - 1 < HALO) continue;                    // (compile time) halo rows only: no output row in this pass
     const int w = rloc + L::RP * i, tt = w - HALO;
     const int tc = max(tt, 0);
@@ -177,15 +198,21 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-      float4 s = db[j];
+      float s[VW];
+#pragma unroll
+      for (int e = 0; e < VW; ++e) s[e] = db[j][e];
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(xn + (tc + k) * C + c0[j]);
-        s.x = fmaf(tap[j][k], v.x, s.x); s.y = fmaf(tap[j][7 + k], v.y, s.y); s.z = fmaf(tap[j][14 + k], v.z, s.z); s.w = fmaf(tap[j][21 + k], v.w, s.w);
+        float v[VW];
+        ldv<VW>(xn + (tc + k) * C + c0[j], v);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s[e] = fmaf(tap[j][7 * e + k], v[e], s[e]);
       }
-      y1[i][j] = make_float4((own[i][j].x + gm[j].x * s.x) * ok, (own[i][j].y + gm[j].y * s.y) * ok, (own[i][j].z + gm[j].z * s.z) * ok,
-                             (own[i][j].w + gm[j].w * s.w) * ok);
-      q += sq4(y1[i][j]);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        y1[i][j][e] = (own[i][j][e] + gm[j][e] * s[e]) * ok;
+        q = fmaf(y1[i][j][e], y1[i][j][e], q);
+      }
     }
     const float s2 = vv_wave_sum(q);
     if (lane == 0) part2[w * 4 + slot] = s2;
@@ -212,12 +239,16 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
         const float rstd = rsqrtf(ss / (float)C + eps);
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-          uint2 p;
-          p.x = pack2(y1[i][j].x * rstd * fw[j].x, y1[i][j].y * rstd * fw[j].y);
-          p.y = pack2(y1[i][j].z * rstd * fw[j].z, y1[i][j].w * rstd * fw[j].w);
-          *reinterpret_cast<uint2*>(xh + tt * L::P1 + c0[j]) = p;
+          if constexpr (VW == 4) {
+            uint2 p;
+            p.x = pack2(y1[i][j][0] * rstd * fw[j][0], y1[i][j][1] * rstd * fw[j][1]);
+            p.y = pack2(y1[i][j][2] * rstd * fw[j][2], y1[i][j][3] * rstd * fw[j][3]);
+            *reinterpret_cast<uint2*>(xh + tt * L::P1 + c0[j]) = p;
+          } else {
+            *reinterpret_cast<unsigned int*>(xh + tt * L::P1 + c0[j]) = pack2(y1[i][j][0] * rstd * fw[j][0], y1[i][j][1] * rstd * fw[j][1]);
+          }
           const bool mine = c0[j] >= ys0 && c0[j] < ys0 + C / (int)gridDim.x;
-          if (mine && tt < rows) *reinterpret_cast<float4*>(y + (int64_t)(t0 + tt) * C + c0[j]) = y1[i][j];
+          if (mine && tt < rows) stv<VW>(y + (int64_t)(t0 + tt) * C + c0[j], y1[i][j]);
         }
       }
     }
@@ -390,7 +421,8 @@ int launch_c(const vv_block& B, const float* x, float* y, void* hidden, float* h
 // rows per workgroup of ffn_in.  Every hidden block of a row tile recomputes the tile's mixer, and with one wave per SIMD that part is
 // bound by instruction issue (tools/convffn_phase.py: 9 of 12 us at C = 512 with 32-row tiles): short tiles cut it, at the price of
 // re-reading W1 once per tile from L2.
-int g_trv512 = 8, g_trv256 = 16;
+int g_trv512 = 8, g_trv256 = 16, g_trv128 = 32;
+int g_c128 = 1;       // the C = 128 stage on the two-launch kernels instead of the one-launch block kernel
 
 }  // namespace
 
@@ -402,7 +434,11 @@ extern "C" int vv_convffn_debug_times(unsigned long long* out8, int reset) {
 }
 #endif
 void vv_convffn_set(int on) { g_on = on; }
-void vv_convffn_set_rows(int c, int rows) { if (c == 512) g_trv512 = rows; else if (c == 256) g_trv256 = rows; }
+void vv_convffn_set_rows(int c, int rows) { if (c == 512) g_trv512 = rows; else if (c == 256) g_trv256 = rows; else if (c == 128) g_trv128 = rows; }
+void vv_convffn_set_c128(int on) { g_c128 = on; }
+// the C = 128 stage of a streaming frame (T = 800 rows): two launches on 400 + 400 workgroups instead of the one-launch block kernel, whose
+// 25 workgroups each pull the full 262 KB weight set through one CU
+bool vv_convffn_prefers(int wdt, int T, int C) { return g_on && g_c128 && wdt == VV_BF16 && C == 128 && T >= 3 && T <= 1024; }
 void vv_skinny_set(int on, int min_m, int max_m) { g_skinny = on; if (min_m > 0) g_skinny_min_m = min_m; if (max_m > 0) g_skinny_max_m = max_m; }
 
 // 1 = launched, 0 = not covered
@@ -429,7 +465,7 @@ int vv_convffn_init() {
   { constexpr int l_ = (int)InLay<CC, TT>::LDS;                                                                                            \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<CC, TT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, l_) != hipSuccess) \
       return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit"); }
-  VV_CF_ATTR(256, 8) VV_CF_ATTR(256, 16) VV_CF_ATTR(256, 32) VV_CF_ATTR(512, 8) VV_CF_ATTR(512, 16) VV_CF_ATTR(512, 32) VV_CF_ATTR(1024, 8)
+  VV_CF_ATTR(128, 16) VV_CF_ATTR(128, 32) VV_CF_ATTR(256, 8) VV_CF_ATTR(256, 16) VV_CF_ATTR(256, 32) VV_CF_ATTR(512, 8) VV_CF_ATTR(512, 16) VV_CF_ATTR(512, 32) VV_CF_ATTR(1024, 8)
 #undef VV_CF_ATTR
   {
     constexpr int l1 = (int)InLay<2048, 1>::LDS;
@@ -460,7 +496,8 @@ int vv_launch_ffn_in_row(const vv_block& B, int wdt, const float* x, float* y, f
 // (out may be y).  hist_new: 6 * C floats of scratch.  1 = enqueued, 0 = not covered (caller runs mixer + two linears), < 0 = error
 int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, int C, float eps,
                       hipStream_t s) {
-  if (!g_on || wdt != VV_BF16 || T < 3 || T > 256 || (C != 256 && C != 512 && C != 1024) || (C == 1024 && T > 64)) return 0;
+  if (!g_on || wdt != VV_BF16 || T < 3 || (C != 128 && C != 256 && C != 512 && C != 1024) || (C == 1024 && T > 64)) return 0;
+  if (C == 128 ? (!g_c128 || T > 1024) : T > 256) return 0;
   auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
   if (!a16(B.w1) || !a16(B.w2) || !a16(B.b1) || !B.b2 || !a16(B.gamma) || !B.ffn_gamma || !a16(B.norm_w) || !a16(B.ffn_norm_w) || !a16(B.dw_b) ||
       !a16(B.dw_w) || !a16(x) || !a16(y) || !a16(hidden) || !a16(hist_new) || !out || (B.hist && !a16(B.hist)))
@@ -468,6 +505,10 @@ int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void
   {   // workgroups read x (and halo rows) while others already write y / hidden: the ranges must be disjoint
     const uintptr_t xa = (uintptr_t)x, ya = (uintptr_t)y, bytes = (uintptr_t)T * C * 4;
     if (xa < ya + bytes && ya < xa + bytes) return 0;
+  }
+  if (C == 128) {
+    if (g_trv128 == 16) return launch_c<128, 16, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
+    return launch_c<128, 32, 4>(B, x, y, hidden, hist_new, out, T, eps, s);
   }
   if (C == 256) {
     if (g_trv256 == 8) return launch_c<256, 8, 4>(B, x, y, hidden, hist_new, out, T, eps, s);

@@ -71,6 +71,8 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "convffn_t1")) { vv_convffn_set_t1(value); return 0; }
   if (key && !strcmp(key, "convffn_rows512")) { vv_convffn_set_rows(512, value); return 0; }
   if (key && !strcmp(key, "convffn_rows256")) { vv_convffn_set_rows(256, value); return 0; }
+  if (key && !strcmp(key, "convffn_rows128")) { vv_convffn_set_rows(128, value); return 0; }
+  if (key && !strcmp(key, "convffn_c128")) { vv_convffn_set_c128(value); return 0; }
   if (key && !strcmp(key, "skinny")) { vv_skinny_set(value, 0, 0); return 0; }
   if (key && !strcmp(key, "skinny_min_m")) { vv_skinny_set(1, value, 0); return 0; }
   if (key && !strcmp(key, "skinny_max_m")) { vv_skinny_set(1, 0, value); return 0; }

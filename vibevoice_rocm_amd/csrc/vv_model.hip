@@ -380,7 +380,7 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
   for (int j = 0; j < nb; ++j) {
     const vv_block& B = net->blocks[stage][j];
     const bool last = (j == nb - 1);
-    {   // narrow stages with many rows: the whole block as one launch (vv_block1d.hip)
+    if (!vv_convffn_prefers(net->wdt, (int)T, C)) {   // narrow stages with many rows: the whole block as one launch (vv_block1d.hip)
       float* dst = last ? (next_pad ? next_pad : other) + (size_t)nctx * C : other;
       const int fused = vv_launch_block1d(B, net->wdt, cur, dst, (int)T, C, net->eps, (hipStream_t)stream);
       if (fused < 0) return fused;
