@@ -68,6 +68,7 @@ int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStre
 int vv_block1d_init();                                            // vv_block1d.hip
 int vv_launch_block1d(const vv_block& B, int wdt, const float* x, float* out, int T, int C, float eps, hipStream_t s);   // 1 launched, 0 not covered
 void vv_block1d_set_fused(int on);
+void vv_block1d_set_blocks(int b);
 int vv_convffn_init();                                            // vv_convffn.hip
 int vv_launch_convffn(const vv_block& B, int wdt, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, int C, float eps,
                       hipStream_t s);                            // 1 launched, 0 not covered

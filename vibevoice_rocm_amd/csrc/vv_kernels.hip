@@ -64,6 +64,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
   if (key && !strcmp(key, "mixer_rows")) { vv_mixer_set_rows(value); return 0; }
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
+  if (key && !strcmp(key, "block1d_blocks")) { vv_block1d_set_blocks(value); return 0; }
   if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
   if (key && !strcmp(key, "gemv_mfma")) { vv_gemv_mfma_set(value, 0); return 0; }
   if (key && !strcmp(key, "gemv_mfma_nopro")) { vv_gemv_mfma_set(1, 0); vv_gemv_mfma_set_nopro(value); return 0; }
