@@ -254,6 +254,9 @@ typedef struct vv_block {
   const void* w2; const float* b2;  /* [C, 4C] */
   float* hist;                      /* [6, C] streaming state or NULL */
   vv_w8 q_w1, q_w2;                 /* used when the block runs as GEMVs (T <= 2 rows: stage 0 of a streaming frame) */
+  const float* dw_last;             /* optional [C]: dw_w[:, 6] packed (the tap of the newest row); with hs: one-row frames skip the 7-row window */
+  float* hs;                        /* optional [C] streaming state next to hist: sum_k<6 dw_w[c, k] * hist[k, c], kept in step with hist by
+                                       the composites (zero when hist is zero); NULL = recompute from hist every frame */
 } vv_block;
 
 /* One whole Block1D (mixer + FFN, vibevoice/modular/modular_vibevoice_tokenizer.py:555-600) as a single launch: x[T, C] -> out[T, C]

@@ -392,3 +392,59 @@ def test_engine_streams_are_recycled(big):
         gc.collect()
     assert len(seen) == 1, f"4 engines in sequence used {len(seen)} different streams"
     assert any(s.cuda_stream in seen for s in E._IDLE_STREAMS.get("cuda:0", []))
+
+
+def test_one_row_stage_state_paths_1p5b_vs_oracle(big):
+    """The one-row stage (C = 2048) carries hs = sum_k<6 tap_k * hist_k next to the history (vv_block.hs).  Seven streaming decoder calls at
+    1.5B against the oracle's streaming decoder: two single frames, a RESET (set_to_zero), a single frame, a TWO-frame call (T = 2 at
+    C = 2048: the general mixer path, after which hs must follow the history), two more single frames - once with the hs kernel, once
+    with the window-rebuilding kernel (vv_tune convffn_t1hs = 0), once with the mixer as its own launch (convffn_t1 = 0).  All three
+    must agree with the oracle (bf16 bar), and the first two with each other within bf16 noise (measured 3.5e-3: the bf16 images of the FFN
+    input round differently when the fp32 sums are taken in a different order)."""
+    from oracle import vv_oracle as O
+    cfg, sd, m = big
+    eng = m.engine
+    Wd = _cpu(sd, "model.acoustic_tokenizer.decoder.")
+    ocfg = cfg.as_dict()
+    plan = [1, 1, "reset", 1, 2, 1, 1]
+    g = torch.Generator().manual_seed(17)
+    lats = [torch.randn(cfg.ac_dim, n, generator=g) for n in plan if n != "reset"]
+    st = O.ConvState()
+    refs, it = [], iter(lats)
+    for n in plan:
+        if n == "reset":
+            st = O.ConvState()
+            continue
+        refs.append(O.tokenizer_decoder(Wd, ocfg, next(it), st)[0])
+    outs = {}
+    ws2 = torch.empty(eng.lib.vv_convnet_ws_bytes(C.byref(eng.w.dec), 2, 1), dtype=torch.uint8, device="cuda")
+    for mode, tunes in (("hs", ((b"convffn_t1", 1), (b"convffn_t1hs", 1))), ("window", ((b"convffn_t1", 1), (b"convffn_t1hs", 0))),
+                        ("mixer", ((b"convffn_t1", 0), (b"convffn_t1hs", 1)))):
+        for k, v in tunes:
+            eng.lib.vv_tune(k, v)
+        try:
+            with torch.cuda.stream(eng.stream):
+                eng.reset_speech_caches()
+            got, it = [], iter(lats)
+            for n in plan:
+                with torch.cuda.stream(eng.stream):
+                    if n == "reset":
+                        eng.reset_speech_caches()
+                        continue
+                    lat = next(it).t().contiguous().cuda()                     # [n, vae] channels-last
+                    wav = torch.empty(n * cfg.hop, device="cuda")
+                    eng._ck(eng.lib.vv_decoder_forward(C.byref(eng.w.dec), lat.data_ptr(), n, 1.0, 0.0, wav.data_ptr(), ws2.data_ptr(), eng.sp), "dec")
+                eng.stream.synchronize()
+                got.append(wav.cpu())
+            outs[mode] = got
+        finally:
+            eng.lib.vv_tune(b"convffn_t1", 1)
+            eng.lib.vv_tune(b"convffn_t1hs", 1)
+        for i, (a, r) in enumerate(zip(got, refs)):
+            e = rel_rms(a.numpy(), r.numpy())
+            assert e < 2e-2, f"{mode}: call {i}: rel RMS vs oracle {e:.3e}"
+    for i, (a, b) in enumerate(zip(outs["hs"], outs["window"])):
+        e = rel_rms(a.numpy(), b.numpy())
+        assert e < 1e-2, f"hs kernel vs window kernel, call {i}: rel RMS {e:.3e} (two bf16 pipelines with different fp32 summation orders: bf16 noise)"
+    with torch.cuda.stream(eng.stream):
+        eng.reset_speech_caches()

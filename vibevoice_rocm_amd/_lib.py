@@ -67,7 +67,7 @@ class DpmCoef(C.Structure):
 
 class Block(C.Structure):
     _fields_ = [("gamma", vp), ("ffn_gamma", vp), ("norm_w", vp), ("ffn_norm_w", vp), ("dw_w", vp), ("dw_b", vp),
-                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("hist", vp), ("q_w1", W8), ("q_w2", W8)]
+                ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("hist", vp), ("q_w1", W8), ("q_w2", W8), ("dw_last", vp), ("hs", vp)]
 
 
 class Conv(C.Structure):

@@ -298,6 +298,123 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
   CSTAMP(6);                                       // combine + GELU + store
 }
 
+
+// ---- the one-row stage with the history part of the depthwise conv carried as state --------------------------------------------------------
+// A frame is ONE row at C = 2048: conv(row) = b + sum_k<6 tap_k * hist_k + tap_6 * RMSNorm(x).  ffn_in_kernel<2048, 1> rebuilds the first two
+// terms in each of its 256 workgroups from 6 history rows and 7 taps per channel: 105 KB of the 277 KB a workgroup requests.  With
+// hs = sum_k<6 tap_k * hist_k kept next to the history (vv_block.hs, refreshed by the net's closing scatter from the rows it stores) and the
+// newest row's tap packed (vv_block.dw_last) a workgroup needs 7 vectors of C floats and no window: y = x + gamma (b + hs + dw_last * xn).
+__global__ __launch_bounds__(256) void ffn_in_row_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ hidden,
+                                                         float* __restrict__ hist_new, const vv_block B, float eps) {
+  constexpr int C = 2048, P1 = C + 8, ST = C / 64;
+  __shared__ __attribute__((aligned(16))) bf16_t xh[P1];
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float part[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * 32;
+  const int lm = lane & 31, hk = (lane >> 5) * 8;
+  float xv[2][4], hsv[2][4], dl[2][4], nw[2][4], db[2][4], gm[2][4], fw[2][4];
+  int c0[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    c0[j] = 4 * (tid + 256 * j);
+    ldv<4>(x + c0[j], xv[j]);
+    ldv<4>(B.norm_w + c0[j], nw[j]);
+    ldv<4>(B.hs + c0[j], hsv[j]);
+    ldv<4>(B.dw_last + c0[j], dl[j]);
+    ldv<4>(B.dw_b + c0[j], db[j]);
+    ldv<4>(B.gamma + c0[j], gm[j]);
+    ldv<4>(B.ffn_norm_w + c0[j], fw[j]);
+  }
+  const bool keeper = hist_new && blockIdx.x == 0;                 // workgroup 0 also shifts the history: rows 1..5 move up, the new row goes last
+  float hrow[5][2][4];
+  if (keeper) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) ldv<4>(B.hist + (size_t)(r + 1) * C + c0[j], hrow[r][j]);
+  }
+  u32x4 wf[ST];
+  {
+    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w1) + (int64_t)(n0 + lm) * C + wave * (C / 4) + hk;
+#pragma unroll
+    for (int s = 0; s < ST; ++s) wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
+  }
+  const int eg = wave;
+  const float4 b1v = *reinterpret_cast<const float4*>(B.b1 + n0 + 8 * eg + 4 * (lane >> 5));
+  __builtin_amdgcn_sched_barrier(0);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q = fmaf(xv[j][e], xv[j][e], q);
+  q = vv_wave_sum(q);
+  if (lane == 0) part[wave] = q;
+  __syncthreads();
+  const float rstd1 = rsqrtf(((part[0] + part[1]) + (part[2] + part[3])) / (float)C + eps);
+  float yv[2][4], xn[2][4];
+  float q2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xn[j][e] = xv[j][e] * rstd1 * nw[j][e];
+      const float sc = db[j][e] + hsv[j][e] + dl[j][e] * xn[j][e];
+      yv[j][e] = xv[j][e] + gm[j][e] * sc;
+      q2 = fmaf(yv[j][e], yv[j][e], q2);
+    }
+  q2 = vv_wave_sum(q2);
+  if (lane == 0) part[4 + wave] = q2;
+  if (keeper) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 5; ++r) stv<4>(hist_new + (size_t)r * C + c0[j], hrow[r][j]);
+      stv<4>(hist_new + (size_t)5 * C + c0[j], xn[j]);
+    }
+  }
+  __syncthreads();
+  const float rstd2 = rsqrtf(((part[4] + part[5]) + (part[6] + part[7])) / (float)C + eps);
+  {
+    const int ys0 = blockIdx.x * (C / (int)gridDim.x);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint2 p;
+      p.x = pack2(yv[j][0] * rstd2 * fw[j][0], yv[j][1] * rstd2 * fw[j][1]);
+      p.y = pack2(yv[j][2] * rstd2 * fw[j][2], yv[j][3] * rstd2 * fw[j][3]);
+      *reinterpret_cast<uint2*>(xh + c0[j]) = p;
+      if (c0[j] >= ys0 && c0[j] < ys0 + C / (int)gridDim.x) stv<4>(y + c0[j], yv[j]);
+    }
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  {
+    const bf16_t* xf = xh + wave * (C / 4) + hk;                   // every tile column reads the one row
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      const u32x4 xb = *reinterpret_cast<const u32x4*>(xf + s * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if ((lane & 31) == 0) {
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 16 + 4 * eg + i) * 64 + lane];
+      v[i] = s;
+    }
+    *reinterpret_cast<float4*>(hidden + n0 + 8 * eg + 4 * (lane >> 5)) =
+        make_float4(vv_gelu_as(v[0] + b1v.x), vv_gelu_as(v[1] + b1v.y), vv_gelu_as(v[2] + b1v.z), vv_gelu_as(v[3] + b1v.w));
+  }
+}
+
 // out[T, C] = res + ffn_gamma * (W2 hidden + b2), hidden bf16 [T, 4C]
 template <int C, int NW>
 __global__ __launch_bounds__(64 * NW) void ffn_out_kernel(const bf16_t* __restrict__ hidden, const float* res, float* out, const float* __restrict__ hist_new,
@@ -489,6 +606,20 @@ int vv_launch_ffn_in_row(const vv_block& B, int wdt, const float* x, float* y, f
     return 0;
   constexpr size_t lds = InLay<2048, 1>::LDS;
   hipLaunchKernelGGL((ffn_in_kernel<2048, 1, true>), dim3(4 * 2048 / 32, 1), dim3(256), lds, s, x, y, hidden, hist_new, 1, B, eps);
+  return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
+}
+
+int g_t1hs = 1;
+void vv_convffn_set_t1hs(int on) { g_t1hs = on; }
+
+// the same with vv_block.hs / dw_last (see ffn_in_row_kernel); 1 = enqueued, 0 = not covered
+int vv_launch_ffn_in_row_hs(const vv_block& B, int wdt, const float* x, float* y, float* hidden, float* hist_new, int C, float eps, hipStream_t s) {
+  if (!g_on || !g_t1 || !g_t1hs || wdt != VV_BF16 || C != 2048 || !B.hist || !B.hs || !B.dw_last) return 0;
+  auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
+  if (!a16(B.w1) || !a16(B.b1) || !a16(B.gamma) || !a16(B.norm_w) || !a16(B.ffn_norm_w) || !a16(B.dw_b) || !a16(B.dw_last) || !a16(B.hs) || !a16(x) ||
+      !a16(y) || !a16(hidden) || !a16(hist_new) || !a16(B.hist) || x == y)
+    return 0;
+  hipLaunchKernelGGL(ffn_in_row_kernel, dim3(4 * 2048 / 32), dim3(256), 0, s, x, y, hidden, hist_new, B, eps);
   return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
 }
 

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int6
 // ---------------------------------------------------------------------------------------------------------------
 // streaming conv contexts of a whole tokenizer
 // ---------------------------------------------------------------------------------------------------------------
-struct CtxItem { float* pad; float* state; int ctx, T, C; };
+struct CtxItem { float* pad; float* state; int ctx, T, C; const float* dw_w; float* hs; };
 struct CtxArgs { CtxItem it[VV_MAX_STAGES + 1 + 16]; int n; };   // convs of a net + the one-row stage's block histories (vv_model.hip)
 
 // gather: pad[0 : ctx] <- state for every conv (before any of them runs)
@@ -348,6 +348,14 @@ __global__ __launch_bounds__(256) void conv_ctx_scatter_kernel(const CtxArgs a) 
   for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += gridDim.x * 1024) {
     if (i + 3 < n && (n & 3) == 0 && (((int64_t)it.T * it.C) & 3) == 0) *reinterpret_cast<float4*>(it.state + i) = *reinterpret_cast<const float4*>(src + i);
     else for (int j = i; j < n && j < i + 4; ++j) it.state[j] = src[j];
+  }
+  if (it.hs) {     // a Block1D history of the one-row stage: its depthwise-conv contribution to the next frame, from the rows just stored
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < it.C; c += gridDim.x * 256) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s = fmaf(it.dw_w[(size_t)c * 7 + k], src[(size_t)k * it.C + c], s);
+      it.hs[c] = s;
+    }
   }
 }
 
@@ -575,6 +583,7 @@ int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStre
   int mx = 0;
   for (int i = 0; i < n; ++i) {
     a.it[i].pad = items[i].pad; a.it[i].state = items[i].state; a.it[i].ctx = items[i].ctx; a.it[i].T = items[i].T; a.it[i].C = items[i].C;
+    a.it[i].dw_w = scatter ? items[i].dw_w : nullptr; a.it[i].hs = scatter ? items[i].hs : nullptr;
     if (items[i].ctx * items[i].C > mx) mx = items[i].ctx * items[i].C;
   }
   int bx = (mx + 1023) / 1024;

@@ -29,7 +29,7 @@ int vv_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* vv_last_error(void) { return g_err; }
-extern "C" int vv_abi_version(void) { return 3; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL)
+extern "C" int vv_abi_version(void) { return 4; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL); 4: vv_block.dw_last / hs, vv_block_mid
 int vv_mixer_init();
 extern "C" int vv_init(void) {
   VV_TRY(vv_mixer_init());
@@ -70,6 +70,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_mfma_nopro")) { vv_gemv_mfma_set(1, 0); vv_gemv_mfma_set_nopro(value); return 0; }
   if (key && !strcmp(key, "gemv_mfma_cap")) { vv_gemv_mfma_set(1, value); return 0; }
   if (key && !strcmp(key, "convffn_t1")) { vv_convffn_set_t1(value); return 0; }
+  if (key && !strcmp(key, "convffn_t1hs")) { vv_convffn_set_t1hs(value); return 0; }
   if (key && !strcmp(key, "convffn_rows512")) { vv_convffn_set_rows(512, value); return 0; }
   if (key && !strcmp(key, "convffn_rows256")) { vv_convffn_set_rows(256, value); return 0; }
   if (key && !strcmp(key, "convffn_rows128")) { vv_convffn_set_rows(128, value); return 0; }

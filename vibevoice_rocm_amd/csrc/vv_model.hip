@@ -395,10 +395,11 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     if (T == 1 && row_hist && items && n_items && j < VV_ROW_BLOCKS && B.hist && !B.q_w1.q) {
       // the one-row stage (C = 2048): mixer + RMSNorm + first GEMM + GELU as one launch (vv_convffn.hip), then the weight-streaming GEMV
       float* hn = row_hist + (size_t)j * 6 * C;
-      const int one = vv_launch_ffn_in_row(B, net->wdt, cur, other, hid, hn, C, net->eps, (hipStream_t)stream);
+      int one = vv_launch_ffn_in_row_hs(B, net->wdt, cur, other, hid, hn, C, net->eps, (hipStream_t)stream);
+      if (one == 0) one = vv_launch_ffn_in_row(B, net->wdt, cur, other, hid, hn, C, net->eps, (hipStream_t)stream);
       if (one < 0) return one;
       if (one) {
-        items[(*n_items)++] = vv_conv_ctx_item{hn, B.hist, 6, 0, C};
+        items[(*n_items)++] = vv_conv_ctx_item{hn, B.hist, 6, 0, C, B.dw_w, B.hs};   // the scatter also refreshes hs from the rows it stores
         float* dst1 = (last && final_dst) ? final_dst : other;
         vv_lin_args a1 = lin_base(hid, 4 * C, 1, B.w2, C, 4 * C, net->wdt, dst1, C);
         a1.bias = B.b2; a1.gate = B.ffn_gamma; a1.gate_ld = 0; a1.res = other; a1.ldres = C;
@@ -409,6 +410,8 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
         continue;
       }
     }
+    if (B.hs && B.hist && items && n_items && *n_items < VV_MAX_STAGES + 1 + VV_ROW_BLOCKS)
+      items[(*n_items)++] = vv_conv_ctx_item{B.hist, B.hist, 6, 0, C, B.dw_w, B.hs};   // this block's history changes below on a general path: hs follows at the closing scatter
     {   // middle stages of a streaming frame (C = 256 / 512): mixer + first GEMM, second GEMM (vv_convffn.hip); the bf16 hidden tile
         // fills the first half of `hid`, the scratch history sits behind it
       float* dst2 = (last && final_dst) ? final_dst : other;
@@ -652,6 +655,10 @@ extern "C" int vv_convnet_reset(const vv_convnet* net, vv_stream_t stream) {
         const vv_block& B = net->blocks[i][j];
         if (B.hist) {
           hipError_t e = hipMemsetAsync(B.hist, 0, (size_t)6 * net->sample[i].cout * 4, s);
+          if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_convnet_reset: %s", hipGetErrorString(e));
+        }
+        if (B.hs) {
+          hipError_t e = hipMemsetAsync(B.hs, 0, (size_t)net->sample[i].cout * 4, s);
           if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_convnet_reset: %s", hipGetErrorString(e));
         }
       }

@@ -271,6 +271,11 @@ class DeviceWeights:
                 h = self._state_zeros(6, ch)
                 self.state_tensors[state_key].append(h)
                 b.hist = L.ptr(h)
+                if ch == 2048 and not qz:
+                    # the one-row stage: the history part of the depthwise conv is carried as state (hs = sum_k<6 tap_k * hist_k, zero with
+                    # hist, inside the same arena so reset / snapshot / rollback cover it) and the newest row's tap is packed
+                    b.dw_last = L.ptr(self._vec(sd[q + "mixer.conv.conv.conv.weight"].reshape(ch, 7)[:, 6].contiguous()))
+                    b.hs = L.ptr(self._state_zeros(1, ch))
             else:
                 b.hist = None
         self._keep.append(arr)
