@@ -309,7 +309,7 @@ def test_matrix_core_gemv_vs_torch(lib, m, n, k, dual, pro, mod, epi, act):
 
 
 @pytest.mark.parametrize("m,n,k,ldx", [(40, 512, 2560, 1280), (200, 256, 1024, 512), (40, 1280, 1024, 1024), (200, 512, 512, 512), (8, 2560, 2048, 2048),
-                                       (37, 48, 2560, 2564), (5, 16, 512, 512), (256, 1024, 1024, 1028), (8, 1024, 5120, 2560)])
+                                       (37, 48, 2560, 2564), (5, 16, 512, 512), (256, 1024, 1024, 1028), (8, 1024, 5120, 2560), (800, 128, 256, 128), (1600, 64, 128, 64), (1603, 32, 128, 132)])
 def test_resampling_conv_skinny_gemm_vs_torch(lib, m, n, k, ldx):
     """vv_linear at the shapes of a streaming frame's resampling convs (fp32 rows with overlapping windows: ldx < k for a strided conv,
     bf16 weights, bias, no activation): the LDS-free skinny kernel of vv_convffn.hip against torch on the bf16-rounded operands."""

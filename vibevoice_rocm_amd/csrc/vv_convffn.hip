@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const float* __restrict__ x
   }
 }
 
-int g_skinny = 1, g_skinny_min_m = 5, g_skinny_max_m = 256;
+int g_skinny = 1, g_skinny_min_m = 5, g_skinny_max_m = 2048;   // up to the T = 1600 rows of the 64 -> 32 / 32 -> 64 resampling convs
 
 int g_on = 1;
 
@@ -566,6 +566,8 @@ int vv_launch_skinny(const vv_lin_args& a, hipStream_t s) {
   const bf16_t* W = reinterpret_cast<const bf16_t*>(a.w);
 #define VV_SK(NSTV, NBV) hipLaunchKernelGGL((skinny_kernel<NSTV, NBV>), grid, dim3(256), 0, s, a.x, a.ldx, a.m, W, a.k, a.bias, a.out, a.ldo)
   switch (a.k) {
+    case 128: VV_SK(1, 1); break;
+    case 256: VV_SK(2, 1); break;
     case 512: VV_SK(4, 1); break;
     case 1024: VV_SK(8, 1); break;
     case 2048: VV_SK(16, 1); break;
