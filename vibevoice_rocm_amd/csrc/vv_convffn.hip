@@ -49,22 +49,23 @@ __device__ __forceinline__ unsigned int pack2(float a, float b) {
 }
 __device__ __forceinline__ float sq4(const float4 v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 
-template <int C, int TRV> struct InLay {                  // TRV: sequence rows per workgroup (<= 32; the MFMA tile stays 32 wide)
+template <int C, int TRV, int NT = 256> struct InLay {    // TRV: sequence rows per workgroup (<= 32; the MFMA tile stays 32 wide); NT: threads
   static constexpr int VW = C >= 256 ? 4 : 2;             // floats per thread per column group (C = 128: 64 threads x float2 keep a wave inside one row)
   static constexpr int F4 = C / 4;                        // float4 columns per row (history copy)
   static constexpr int FV = C / VW;                       // column groups per row
-  static constexpr int TPR = FV < 256 ? FV : 256;         // threads per row
+  static constexpr int TPR = FV < NT ? FV : NT;           // threads per row
+  static constexpr int NWV = NT / 64;                     // waves: they split the window rows in the mixer part and K in the GEMM
   static constexpr int CPT = FV / TPR;                    // column groups per thread per row (2 at C = 2048)
-  static constexpr int RP = 256 / TPR;                    // window rows per pass of the 256 threads
+  static constexpr int RP = NT / TPR;                     // window rows per pass of the workgroup
   static constexpr int NI = (TRV + HALO + RP - 1) / RP;   // passes over the window (TRV + 6 rows)
   static constexpr int WR = NI * RP;                      // window rows held in LDS (>= TRV + 6: no row guards on the LDS side)
   static constexpr int WPR = TPR / 64;                    // waves per row (partial sums of squares per row)
   static constexpr int P1 = C + 8;                        // bf16 pitch of the FFN input image
-  static constexpr int ST = C / 64;                       // MFMA steps of one wave (K split over the 4 waves)
+  static constexpr int ST = C / (16 * NWV);               // MFMA steps of one wave (K split over the waves)
   static constexpr size_t XN = (size_t)WR * C * 4;
-  static constexpr size_t RED = (size_t)4 * 16 * 64 * 4;  // K-split partial accumulators (alias the window once it is consumed)
+  static constexpr size_t RED = (size_t)NWV * 16 * 64 * 4;   // K-split partial accumulators (alias the window once it is consumed)
   static constexpr size_t XH = (size_t)(WR - HALO) * P1 * 2;
-  static constexpr size_t PART = (size_t)2 * WR * 4 * 4;
+  static constexpr size_t PART = (size_t)2 * WR * 8 * 4;
   static constexpr size_t LDS = (XN > RED ? XN : RED) + XH + PART;
 };
 
@@ -79,11 +80,11 @@ template <int VW> __device__ __forceinline__ void stv(float* p, const float (&o)
 }
 
 // HF32: the hidden tile is written in fp32 (the T = 1 stage, whose second GEMM stays on the weight-streaming GEMV)
-template <int C, int TRV, bool HF32>
-__global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, void* __restrict__ hidden_v,
+template <int C, int TRV, bool HF32, int NT>
+__global__ __launch_bounds__(NT) void ffn_in_kernel(const float* __restrict__ x, float* __restrict__ y, void* __restrict__ hidden_v,
                                                      float* __restrict__ hist_new, int T, const vv_block B, float eps) {
-  using L = InLay<C, TRV>;
-  constexpr int TR = TRV, CPT = L::CPT, VW = L::VW;
+  using L = InLay<C, TRV, NT>;
+  constexpr int TR = TRV, CPT = L::CPT, VW = L::VW, NWV = L::NWV;
 #ifdef VV_CF_TIMING
   long long tprev_ = wall_clock64();
 #endif
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
   float* xn = reinterpret_cast<float*>(smem);                                        // [WR][C] normalised window
   float* red = reinterpret_cast<float*>(smem);                                       // aliases xn after the conv
   bf16_t* xh = reinterpret_cast<bf16_t*>(smem + (L::XN > L::RED ? L::XN : L::RED));  // [WR - 6][P1] RMSNorm(y) in bf16
-  float* part = reinterpret_cast<float*>(smem + (L::XN > L::RED ? L::XN : L::RED) + L::XH);   // [2][WR][4]
-  float* part2 = part + L::WR * 4;
+  float* part = reinterpret_cast<float*>(smem + (L::XN > L::RED ? L::XN : L::RED) + L::XH);   // [2][WR][8]
+  float* part2 = part + L::WR * 8;
   // The wave index goes through readfirstlane: everything derived from it (window row, validity, LDS rows) is then wave-uniform for the
   // compiler - scalar address arithmetic and scalar selects.  The mixer part of this kernel is bound by instruction issue (one wave per
   // SIMD, tools/convffn_phase.py), so guards are written as selects / 0-1 factors on always-valid addresses, not as branches.
@@ -141,11 +142,11 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
   }
   u32x4 wf[L::ST];
   {
-    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w1) + (int64_t)(n0 + lm) * C + wave * (C / 4) + hk;
+    const bf16_t* wr = reinterpret_cast<const bf16_t*>(B.w1) + (int64_t)(n0 + lm) * C + wave * (C / NWV) + hk;
 #pragma unroll
     for (int s = 0; s < L::ST; ++s) wf[s] = *reinterpret_cast<const u32x4*>(wr + s * 16);
   }
-  const int eg = wave;                                             // epilogue: this thread finishes channels n0 + 8 eg + 4 (lane >> 5) + {0..3}
+  const int eg = wave & 3;                                         // epilogue (waves 0..3): this thread finishes channels n0 + 8 eg + 4 (lane >> 5) + {0..3}
   const float4 b1v = *reinterpret_cast<const float4*>(B.b1 + n0 + 8 * eg + 4 * (lane >> 5));
   __builtin_amdgcn_sched_barrier(0);                               // nothing below is scheduled in front of these requests
 
@@ -160,16 +161,16 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 #pragma unroll
       for (int e = 0; e < VW; ++e) q = fmaf(own[i][j][e], own[i][j][e], q);
     const float s = vv_wave_sum(q);
-    if (lane == 0) part[w * 4 + slot] = s;
+    if (lane == 0) part[w * 8 + slot] = s;
   }
   __syncthreads();
   CSTAMP(1);                                       // loads landed, row statistics, barrier
 #pragma unroll
   for (int i = 0; i < L::NI; ++i) {
     const int w = rloc + L::RP * i, t = t0 - HALO + w;
-    float ss = part[w * 4];
+    float ss = part[w * 8];
 #pragma unroll
-    for (int sl = 1; sl < L::WPR; ++sl) ss += part[w * 4 + sl];
+    for (int sl = 1; sl < L::WPR; ++sl) ss += part[w * 8 + sl];
     const bool isx = t >= 0;                                       // history rows are stored normalised; rows past the sequence are zeros
     const float rstd = isx ? rsqrtf(ss / (float)C + eps) : 1.f;
 #pragma unroll
@@ -215,11 +216,11 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
       }
     }
     const float s2 = vv_wave_sum(q);
-    if (lane == 0) part2[w * 4 + slot] = s2;
+    if (lane == 0) part2[w * 8 + slot] = s2;
   }
   // the new streaming history = the last 6 rows of [old history ; normalised rows]: all inside the LAST row tile's window
   if (hist_new && blockIdx.x == 0 && t0 + TR >= T) {
-    for (int e = tid; e < HALO * L::F4; e += 256) {
+    for (int e = tid; e < HALO * L::F4; e += NT) {
       const int j = e / L::F4, c4 = e - j * L::F4;
       *reinterpret_cast<float4*>(hist_new + (size_t)j * C + 4 * c4) = *reinterpret_cast<const float4*>(xn + (size_t)(T - t0 + j) * C + 4 * c4);
     }
@@ -233,9 +234,9 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
       if (L::RP * i + L::RP - 1 < HALO) continue;
       const int w = rloc + L::RP * i, tt = w - HALO;
       if (tt >= 0) {                                                // (wave-uniform; rows past the end of the sequence hold zeros)
-        float ss = part2[w * 4];
+        float ss = part2[w * 8];
 #pragma unroll
-        for (int sl = 1; sl < L::WPR; ++sl) ss += part2[w * 4 + sl];
+        for (int sl = 1; sl < L::WPR; ++sl) ss += part2[w * 8 + sl];
         const float rstd = rsqrtf(ss / (float)C + eps);
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   {
-    const bf16_t* xf = xh + min(lm, TR - 1) * L::P1 + wave * (C / 4) + hk;     // tile columns past TR repeat a row (never stored)
+    const bf16_t* xf = xh + min(lm, TR - 1) * L::P1 + wave * (C / NWV) + hk;   // tile columns past TR repeat a row (never stored)
 #pragma unroll
     for (int s = 0; s < L::ST; ++s) {
       const u32x4 xb = *reinterpret_cast<const u32x4*>(xf + s * 16);
@@ -274,13 +275,13 @@ __global__ __launch_bounds__(256) void ffn_in_kernel(const float* __restrict__ x
   CSTAMP(5);                                       // MFMA + partials
   {
     const int m = lane & 31;
-    if (m < rows) {
+    if (m < rows && wave < 4) {
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float s = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) s += red[(w4 * 16 + 4 * eg + i) * 64 + lane];   // fixed order: deterministic
+        for (int w4 = 0; w4 < NWV; ++w4) s += red[(w4 * 16 + 4 * eg + i) * 64 + lane];   // fixed order: deterministic
         v[i] = s;
       }
       const float g0 = vv_gelu_as(v[0] + b1v.x), g1 = vv_gelu_as(v[1] + b1v.y), g2 = vv_gelu_as(v[2] + b1v.z), g3 = vv_gelu_as(v[3] + b1v.w);
@@ -526,11 +527,15 @@ int g_skinny = 1, g_skinny_min_m = 5, g_skinny_max_m = 2048;   // up to the T = 
 
 int g_on = 1;
 
+// threads of ffn_in per channel count: the mixer part is instruction-issue bound, so the wide stages spread it over 8 waves
+template <int C> constexpr int in_threads() { return (C == 512 || C == 1024) ? 512 : 256; }
+
 template <int C, int TRV, int NW>
 int launch_c(const vv_block& B, const float* x, float* y, void* hidden, float* hist_new, float* out, int T, float eps, hipStream_t s) {
   float* hn = B.hist ? hist_new : nullptr;
-  constexpr size_t lds = InLay<C, TRV>::LDS;
-  hipLaunchKernelGGL((ffn_in_kernel<C, TRV, false>), dim3(4 * C / 32, (T + TRV - 1) / TRV), dim3(256), lds, s, x, y, hidden, hn, T, B, eps);
+  constexpr int NT = in_threads<C>();
+  constexpr size_t lds = InLay<C, TRV, NT>::LDS;
+  hipLaunchKernelGGL((ffn_in_kernel<C, TRV, false, NT>), dim3(4 * C / 32, (T + TRV - 1) / TRV), dim3(NT), lds, s, x, y, hidden, hn, T, B, eps);
   hipLaunchKernelGGL((ffn_out_kernel<C, NW>), dim3(C / 16, (T + TR2 - 1) / TR2), dim3(64 * NW), 0, s, reinterpret_cast<const bf16_t*>(hidden), y, out, hn, T, B);
   return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
 }
@@ -581,14 +586,14 @@ int vv_launch_skinny(const vv_lin_args& a, hipStream_t s) {
 
 int vv_convffn_init() {
 #define VV_CF_ATTR(CC, TT)                                                                                                                  \
-  { constexpr int l_ = (int)InLay<CC, TT>::LDS;                                                                                            \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<CC, TT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, l_) != hipSuccess) \
+  { constexpr int nt_ = in_threads<CC>(); constexpr int l_ = (int)InLay<CC, TT, nt_>::LDS;                                                 \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<CC, TT, false, nt_>), hipFuncAttributeMaxDynamicSharedMemorySize, l_) != hipSuccess) \
       return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit"); }
   VV_CF_ATTR(128, 16) VV_CF_ATTR(128, 32) VV_CF_ATTR(256, 8) VV_CF_ATTR(256, 16) VV_CF_ATTR(256, 32) VV_CF_ATTR(512, 8) VV_CF_ATTR(512, 16) VV_CF_ATTR(512, 32) VV_CF_ATTR(1024, 8)
 #undef VV_CF_ATTR
   {
-    constexpr int l1 = (int)InLay<2048, 1>::LDS;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<2048, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess)
+    constexpr int l1 = (int)InLay<2048, 1, 256>::LDS;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_in_kernel<2048, 1, true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess)
       return vv_set_error(VV_E_HIP, "vv_convffn_init: cannot raise the LDS limit");
   }
   return 0;
@@ -606,8 +611,8 @@ int vv_launch_ffn_in_row(const vv_block& B, int wdt, const float* x, float* y, f
   if (!a16(B.w1) || !a16(B.b1) || !a16(B.gamma) || !a16(B.norm_w) || !a16(B.ffn_norm_w) || !a16(B.dw_b) || !a16(B.dw_w) || !a16(x) || !a16(y) ||
       !a16(hidden) || !a16(hist_new) || !a16(B.hist) || x == y)
     return 0;
-  constexpr size_t lds = InLay<2048, 1>::LDS;
-  hipLaunchKernelGGL((ffn_in_kernel<2048, 1, true>), dim3(4 * 2048 / 32, 1), dim3(256), lds, s, x, y, hidden, hist_new, 1, B, eps);
+  constexpr size_t lds = InLay<2048, 1, 256>::LDS;
+  hipLaunchKernelGGL((ffn_in_kernel<2048, 1, true, 256>), dim3(4 * 2048 / 32, 1), dim3(256), lds, s, x, y, hidden, hist_new, 1, B, eps);
   return hipGetLastError() == hipSuccess ? 1 : vv_set_error(VV_E_HIP, "vv_convffn: launch failed");
 }
 
