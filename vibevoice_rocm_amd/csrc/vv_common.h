@@ -63,7 +63,7 @@ int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, co
                            const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s);
 int vv_fused_init();
 int vv_head_modulations_fused(const vv_head* h, const void* c_bf16, int rows, float* const* mod, float* modf, hipStream_t s);   // 1 launched, 0 not covered
-struct vv_conv_ctx_item { float* pad; float* state; int ctx, T, C; const float* dw_w; float* hs; };   // dw_w / hs (scatter only): also hs[c] = sum_k<6 dw_w[c, k] * new state[k, c]
+struct vv_conv_ctx_item { float* pad; float* state; int ctx, T, C; const float* dw_w; float* hs; int affine; float scale, bias; };   // dw_w / hs (scatter only): also hs[c] = sum_k<6 dw_w[c, k] * new state[k, c]; affine (gather only): pad = state * scale + bias (the net's input rides along)
 int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStream_t s);   // scatter 0: pad[0:ctx] <- state; 1: state <- pad[T : T + ctx]
 int vv_block1d_init();                                            // vv_block1d.hip
 int vv_launch_block1d(const vv_block& B, int wdt, const float* x, float* out, int T, int C, float eps, hipStream_t s);   // 1 launched, 0 not covered

@@ -328,13 +328,17 @@ __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int6
 // ---------------------------------------------------------------------------------------------------------------
 // streaming conv contexts of a whole tokenizer
 // ---------------------------------------------------------------------------------------------------------------
-struct CtxItem { float* pad; float* state; int ctx, T, C; const float* dw_w; float* hs; };
+struct CtxItem { float* pad; float* state; int ctx, T, C; const float* dw_w; float* hs; int affine; float scale, bias; };
 struct CtxArgs { CtxItem it[VV_MAX_STAGES + 1 + 16]; int n; };   // convs of a net + the one-row stage's block histories (vv_model.hip)
 
 // gather: pad[0 : ctx] <- state for every conv (before any of them runs)
 __global__ __launch_bounds__(256) void conv_ctx_gather_kernel(const CtxArgs a) {
   const CtxItem it = a.it[blockIdx.y];
   const int n = it.ctx * it.C;
+  if (it.affine) {               // the net's own input (latent frame / waveform chunk) into its stem's padded buffer: y = x * scale + bias
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) it.pad[i] = fmaf(it.state[i], it.scale, it.bias);
+    return;
+  }
   for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += gridDim.x * 1024) {
     if (i + 3 < n && (n & 3) == 0) *reinterpret_cast<float4*>(it.pad + i) = *reinterpret_cast<const float4*>(it.state + i);
     else for (int j = i; j < n && j < i + 4; ++j) it.pad[j] = it.state[j];
@@ -433,13 +437,18 @@ __global__ __launch_bounds__(256) void adaln_lds_kernel(const bf16_t* __restrict
   const int r16 = lane & 15, kq = lane >> 4;
   const int kb = wave * (32 * NST) + 8 * kq;
   auto locate = [&](int bx, int& l, int& n0) { l = 0; while (l + 1 < tab.n && bx >= tab.nblk[l]) { bx -= tab.nblk[l]; ++l; } n0 = bx * 16; };
-  ad_u32x4 wcur[NST], wnxt[NST];
+  ad_u32x4 wcur[NST], wnxt[NST], wnn[NST];                         // weights run TWO output blocks ahead of the MFMAs
   int bx = blockIdx.x, l, n0;
   locate(bx, l, n0);
   {
     const bf16_t* wr = tab.w[l] + (int64_t)(n0 + r16) * D + kb;
 #pragma unroll
     for (int s = 0; s < NST; ++s) wcur[s] = *reinterpret_cast<const ad_u32x4*>(wr + 32 * s);
+    int l1, n1;
+    locate(min(bx + (int)gridDim.x, total - 1), l1, n1);
+    const bf16_t* wr1 = tab.w[l1] + (int64_t)(n1 + r16) * D + kb;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) wnxt[s] = *reinterpret_cast<const ad_u32x4*>(wr1 + 32 * s);
   }
   {   // stage the row group: 16-byte chunks, 12 per thread per pass
     constexpr int CPR = D / 8;                                    // chunks per row
@@ -466,13 +475,13 @@ __global__ __launch_bounds__(256) void adaln_lds_kernel(const bf16_t* __restrict
   const int ei = tid >> 6, el = tid & 63;
   int par = 0;
   for (; bx < total; bx += gridDim.x) {
-    const int bn = bx + gridDim.x;
+    const int bn = bx + 2 * gridDim.x;
     if (bn < total) {
       int l2, n2;
       locate(bn, l2, n2);
       const bf16_t* wr = tab.w[l2] + (int64_t)(n2 + r16) * D + kb;
 #pragma unroll
-      for (int s = 0; s < NST; ++s) wnxt[s] = *reinterpret_cast<const ad_u32x4*>(wr + 32 * s);
+      for (int s = 0; s < NST; ++s) wnn[s] = *reinterpret_cast<const ad_u32x4*>(wr + 32 * s);
     }
     ad_f32x4 acc[NM];
 #pragma unroll
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256) void adaln_lds_kernel(const bf16_t* __restrict
     }
     par ^= 1;
 #pragma unroll
-    for (int s = 0; s < NST; ++s) wcur[s] = wnxt[s];
+    for (int s = 0; s < NST; ++s) { wcur[s] = wnxt[s]; wnxt[s] = wnn[s]; }
   }
 }
 
@@ -584,6 +593,7 @@ int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStre
   for (int i = 0; i < n; ++i) {
     a.it[i].pad = items[i].pad; a.it[i].state = items[i].state; a.it[i].ctx = items[i].ctx; a.it[i].T = items[i].T; a.it[i].C = items[i].C;
     a.it[i].dw_w = scatter ? items[i].dw_w : nullptr; a.it[i].hs = scatter ? items[i].hs : nullptr;
+    a.it[i].affine = scatter ? 0 : items[i].affine; a.it[i].scale = items[i].scale; a.it[i].bias = items[i].bias;
     if (items[i].ctx * items[i].C > mx) mx = items[i].ctx * items[i].C;
   }
   int bx = (mx + 1023) / 1024;

@@ -498,10 +498,15 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
       if (conv_ctx_of(cv) > 0) items[n_items++] = vv_conv_ctx_item{pads + poff[i], cv.state, conv_ctx_of(cv), (int)Ti, cv.cin};
       if (cv.transposed) Ti *= cv.stride;
     }
-    VV_TRY(vv_conv_ctx_batch(items, n_items, 0, (hipStream_t)stream));
+    // the scaled latent frame rides along with the context gather: one launch instead of two in front of the stem conv
+    vv_conv_ctx_item gi[VV_MAX_STAGES + 2];
+    for (int i = 0; i < n_items; ++i) gi[i] = items[i];
+    gi[n_items] = vv_conv_ctx_item{pads + poff[0] + (size_t)conv_ctx_of(stem) * stem.cin, const_cast<float*>(latent), (int)T, 0, stem.cin, nullptr, nullptr, 1,
+                                   pre_scale, pre_bias};
+    VV_TRY(vv_conv_ctx_batch(gi, n_items + 1, 0, (hipStream_t)stream));
   }
   float* pad = streaming ? pads + poff[0] : A;
-  VV_TRY(vv_affine(latent, pre_scale, pre_bias, pad + (size_t)conv_ctx_of(stem) * stem.cin, (int64_t)T * stem.cin, stream));
+  if (!streaming) VV_TRY(vv_affine(latent, pre_scale, pre_bias, pad + (size_t)conv_ctx_of(stem) * stem.cin, (int64_t)T * stem.cin, stream));
   float* cur = nullptr;     // current activation buffer, `pad` holds the next conv's input
   float* other = nullptr;
   for (int i = 0; i < net->n_stages; ++i) {
@@ -579,10 +584,15 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
       if (conv_ctx_of(cv) > 0) items[n_items++] = vv_conv_ctx_item{pads + poff[i], cv.state, conv_ctx_of(cv), (int)Ti, cv.cin};
       Ti = (Ti + cv.stride - 1) / cv.stride;
     }
-    VV_TRY(vv_conv_ctx_batch(items, n_items, 0, s));
+    // the waveform chunk rides along with the context gather (no separate copy in front of the stem conv)
+    vv_conv_ctx_item gi[VV_MAX_STAGES + 2];
+    for (int i = 0; i < n_items; ++i) gi[i] = items[i];
+    gi[n_items] = vv_conv_ctx_item{pads + poff[0] + (size_t)conv_ctx_of(stem) * stem.cin, const_cast<float*>(wav), (int)T, 0, stem.cin, nullptr, nullptr, 1, 1.0f, 0.0f};
+    VV_TRY(vv_conv_ctx_batch(gi, n_items + 1, 0, s));
   }
   float* pad = streaming ? pads + poff[0] : A;
-  hipError_t e = hipMemcpyAsync(pad + (size_t)conv_ctx_of(stem) * stem.cin, wav, (size_t)T * stem.cin * 4, hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipSuccess;
+  if (!streaming) e = hipMemcpyAsync(pad + (size_t)conv_ctx_of(stem) * stem.cin, wav, (size_t)T * stem.cin * 4, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_encoder_forward: %s", hipGetErrorString(e));
   float* cur = nullptr;
   float* other = nullptr;
