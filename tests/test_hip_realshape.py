@@ -370,6 +370,11 @@ def test_batch_of_six_shares_streams_and_equals_singles(big):
     assert len(m._lanes) >= B
     streams = [e.stream.cuda_stream for e in m._lanes[:B]]
     assert len(set(streams)) == M.LANES_IN_FLIGHT and streams[4] == streams[0] and streams[5] == streams[1]
+    # lanes use lane 0's device weights as they are (DeviceWeights.fork): same matrices, own streaming state
+    w0, w1 = m._lanes[0].w, m._lanes[1].w
+    assert w1.dec.sample[0].w == w0.dec.sample[0].w and w1.dec.blocks[0][0].w1 == w0.dec.blocks[0][0].w1 and w1.head_g.data_ptr() == w0.head_g.data_ptr()
+    assert w1.dec.blocks[0][0].hist != w0.dec.blocks[0][0].hist and w1.dec.sample[1].state != w0.dec.sample[1].state
+    assert w1.state_blob().data_ptr() != w0.state_blob().data_ptr() and w1.state_blob().numel() == w0.state_blob().numel()
     for b in range(B):
         one = m.generate(input_ids=ids[b][None], tokenizer=tok, cfg_scale=2.0, forced_tokens=forced[b], noise=noise[b])
         assert torch.equal(out.speech_outputs[b], one.speech_outputs[0]), f"sample {b}: batch of 6 differs from its single run"

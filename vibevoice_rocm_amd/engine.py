@@ -35,7 +35,7 @@ _IDLE_STREAMS: Dict[str, list] = {}
 class Engine:
     def __init__(self, cfg: VVConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", dtype=torch.bfloat16,
                  kv_dtype: Optional[torch.dtype] = None, use_graphs: bool = True, bf16_timestep_quirk: Optional[bool] = None,
-                 weight_quant: Optional[str] = None, stream: Optional[torch.cuda.Stream] = None):
+                 weight_quant: Optional[str] = None, stream: Optional[torch.cuda.Stream] = None, weights_from: Optional["Engine"] = None):
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -55,7 +55,9 @@ class Engine:
         L.check(self.lib.vv_init(), "vv_init")          # one-time kernel attributes, before any graph capture
         self.sync_in()
         with torch.cuda.stream(self.stream):
-            self.w = DeviceWeights(cfg, state_dict, self.device, dtype, quant=weight_quant)
+            # weights_from: another engine of the same model on this device - its weights are used as they are (DeviceWeights.fork), only
+            # the streaming state is this engine's own
+            self.w = weights_from.w.fork() if weights_from is not None else DeviceWeights(cfg, state_dict, self.device, dtype, quant=weight_quant)
             H = cfg.hidden
             f32 = dict(dtype=torch.float32, device=self.device)
             self.x2 = torch.zeros(2, H, **f32)            # input embedding of the step, rows {positive, negative}

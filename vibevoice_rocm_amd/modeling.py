@@ -320,7 +320,7 @@ class VibeVoiceForConditionalGenerationInference:
         while len(self._lanes) <= b:
             n = len(self._lanes)             # lanes past LANES_IN_FLIGHT share the stream of lane n % LANES_IN_FLIGHT: see _generate_lockstep
             eng = Engine(self.config, self._state_dict, device=self.device, dtype=self.dtype, use_graphs=self._use_graphs, weight_quant=self.weight_quant,
-                         stream=self._lanes[n % LANES_IN_FLIGHT].stream if n >= LANES_IN_FLIGHT else None)
+                         stream=self._lanes[n % LANES_IN_FLIGHT].stream if n >= LANES_IN_FLIGHT else None, weights_from=self.engine)
             eng.scheduler = self.engine.scheduler
             self._lanes.append(eng)
         eng = self._lanes[b]

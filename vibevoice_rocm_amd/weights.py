@@ -142,6 +142,40 @@ class DeviceWeights:
         self._state_used += (n + 63) // 64 * 64
         return t
 
+    def fork(self) -> "DeviceWeights":
+        """A second set of descriptors over the SAME device weights with a streaming-state arena of its own (a lane of a lock-step batch,
+        a concurrent dialogue): nothing is re-laid-out or copied except the few KB of ctypes descriptors that carry state pointers."""
+        w = object.__new__(DeviceWeights)
+        w.__dict__.update(self.__dict__)
+        w._keep = list(self._keep)
+        w._state_arena = torch.zeros_like(self._state_arena)
+        old0, new0 = self._state_arena.data_ptr(), w._state_arena.data_ptr()
+
+        def reloc(p):
+            return None if not p else new0 + (int(p) - old0)
+
+        def fork_net(net: "L.ConvNet") -> "L.ConvNet":
+            n2 = L.ConvNet.from_buffer_copy(net)
+            for i in range(net.n_stages):
+                n2.sample[i].state = reloc(net.sample[i].state)
+                nb = net.n_blocks[i]
+                if nb > 0:
+                    arr = (L.Block * nb)()
+                    C.memmove(arr, net.blocks[i], C.sizeof(L.Block) * nb)
+                    for j in range(nb):
+                        arr[j].hist = reloc(arr[j].hist)
+                        arr[j].hs = reloc(arr[j].hs)
+                    w._keep.append(arr)
+                    n2.blocks[i] = C.cast(arr, C.POINTER(L.Block))
+            n2.head.state = reloc(net.head.state)
+            return n2
+
+        w.dec, w.sem = fork_net(self.dec), fork_net(self.sem)
+        f32 = 4
+        w.state_tensors = {k: [w._state_arena[(t.data_ptr() - old0) // f32: (t.data_ptr() - old0) // f32 + t.numel()].view_as(t) for t in v]
+                           for k, v in self.state_tensors.items()}
+        return w
+
     def state_blob(self) -> torch.Tensor:
         """All streaming state of the speech path as one flat fp32 tensor."""
         return self._state_arena[: max(self._state_used, 64)]
