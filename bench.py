@@ -418,6 +418,108 @@ def log(msg):
     print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, timeout=None):
+    """Parent of a self-launched N-rank run (no torchrun): one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rank 0's stdout relayed to ours, every rank's stderr inherited.  The parent never touches the GPU (no exec from a process that
+    has).  Returns the exit code: 0 only if every rank returned 0; the first failure ends the other ranks (exact PIDs)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_WORLD_SIZE=str(n))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    log(f"launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    import threading
+    lines = []
+
+    def relay():
+        for ln in procs[0].stdout:
+            lines.append(ln)          # held back until every rank has returned 0: a failed run prints no result line
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    t0, rc = time.time(), 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0:
+                log(f"launcher: rank {r} exited with {c}")
+                rc = rc or (c if c > 0 else 1)
+        if rc or (timeout and time.time() - t0 > timeout):
+            rc = rc or 124
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(10)
+                except Exception:      # noqa: BLE001
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    th.join(5)
+    if rc == 0 and not any(ln.strip().startswith(b"{") for ln in lines):
+        log("launcher: rank 0 printed no JSON line")
+        rc = 1
+    out = sys.stdout if rc == 0 else sys.stderr
+    for ln in lines:
+        out.write(ln.decode(errors="replace"))
+    out.flush()
+    return rc
+
+
+def init_ranks(gpus):
+    """RANK / LOCAL_RANK / WORLD_SIZE from the environment (set by torch.distributed.run or by launch_ranks).  WORLD_SIZE must equal
+    --gpus in every case.  Returns (rank, local_rank, world, dist module or None, backend name or None)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (self-launching) or with "
+                         f"torch.distributed.run --nproc-per-node N")
+    if world == 1:
+        return rank, local_rank, world, None, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("VV_DIST_BACKEND", "nccl")          # "gloo" lets ranks rehearse on one GPU / on the CPU
+    if os.environ.get("VV_ALL_RANKS_ONE_GPU") == "1":
+        local_rank = 0
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    assert dist.get_world_size() == world and dist.get_rank() == rank
+    return rank, local_rank, world, dist, backend
+
+
+def stub_body(args, rank, world, dist, backend):
+    """VV_BENCH_STUB=1: the launcher / rendezvous / timing skeleton with no GPU work (CPU test of the N-rank path)."""
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if dist is not None:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if os.environ.get("VV_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "n_gpus": world, "max_rank_plus_1": float(t.item()),
+                          "rccl": {"ranks": dist.get_world_size() if dist is not None else 1, "backend": backend}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,22 +548,13 @@ def main():
     args.ddpm_steps = args.ddpm_steps or W["steps"]
     headline = args.workload == "cfg2"
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("VV_DIST_BACKEND", "nccl")          # "gloo" lets two ranks rehearse on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    if os.environ.get("VV_ALL_RANKS_ONE_GPU") == "1":
-        local_rank = 0
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process has made no GPU call yet (argparse only) and never will - it starts N
+        # fresh rank processes, relays rank 0's JSON line and leaves with the worst exit code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank, local_rank, world, dist, backend = init_ranks(args.gpus)
+    if os.environ.get("VV_BENCH_STUB") == "1":
+        return stub_body(args, rank, world, dist, backend)
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
 
@@ -474,8 +567,16 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     # rank 0 owns the (random-init) checkpoint; replicas receive it over RCCL/xGMI
     sd = synth_state_dict_torch(cfg, 1234, device=device, dtype=dtype) if rank == 0 else None
+    rccl = None
     if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
         sd = vd.broadcast_state_dict(sd, cfg, dtype, device, src=0)
+        torch.cuda.synchronize()
+        nb = sum(v.numel() * v.element_size() for v in sd.values())
+        rccl = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "bcast": os.environ.get("VV_BCAST", "broadcast"),
+                "bcast_s": round(time.perf_counter() - tb, 4), "bcast_GB": round(nb / 1e9, 3), "gather_ms": []}
     log("weights ready")
     model = VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs,
                                                        weight_quant=W["quant"] if dtype == torch.bfloat16 else None)
@@ -515,7 +616,9 @@ def main():
     for _ in range(args.steps):
         out = gen()
         if dist is not None:
+            tg = time.perf_counter()
             vd.gather_waveforms(out.speech_outputs[0], dst=0)
+            rccl["gather_ms"].append(round(1e3 * (time.perf_counter() - tg), 3))        # includes waiting for the slowest rank's dialogue
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -553,6 +656,11 @@ def main():
                       "note": "whole-frame HBM figure: the diffusion head's weights stay in the 256 MB Infinity Cache across solver steps, so "
                               "frac_if_head_weights_counted_once is the honest HBM utilisation"},
         }
+    if rank == 0 and rccl is not None:
+        rccl["bcast_GBps"] = round(rccl["bcast_GB"] / max(rccl["bcast_s"], 1e-9), 1)
+        rccl["note"] = ("one broadcast of the packed checkpoint before the timed region, one ragged gather of the fp32 waveforms per step inside "
+                        "it (wall time on rank 0: includes waiting for the slowest rank); no collective inside generate()")
+        result["rccl"] = rccl
     if rank == 0 and single:
         result["first_chunk_latency"] = first_chunk_leg(model, wl, args.cfg_scale, runs=args.first_chunk_runs, gen_kw=gen_kw)
         log(f"first-chunk latency p50 {result['first_chunk_latency']['p50_ms']} ms")

@@ -295,3 +295,49 @@ def test_hw_queue_default_is_set_on_import():
     out = subprocess.run([sys.executable, "-c", "import os, vibevoice_rocm_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"], env=env, capture_output=True, text=True,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.stdout.strip() == "4"
+
+
+def _run_bench(env_extra, *argv, timeout=240):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it starts two fresh rank processes (gloo here, stub body: the launcher,
+    rendezvous and relay are the thing under test), relays rank 0's single JSON line and returns 0; a failing rank makes the parent
+    fail and suppresses the result line; WORLD_SIZE != --gpus is an error in every case."""
+    import json
+    r = _run_bench({"VV_BENCH_STUB": "1", "VV_DIST_BACKEND": "gloo"}, "--gpus", "2")
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl"] == {"ranks": 2, "backend": "gloo"} and j["max_rank_plus_1"] == 2.0
+    r = _run_bench({"VV_BENCH_STUB": "1", "VV_DIST_BACKEND": "gloo", "VV_BENCH_STUB_FAIL_RANK": "1"}, "--gpus", "2")
+    assert r.returncode == 3 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], (r.returncode, r.stdout)
+    r = _run_bench({"VV_BENCH_STUB": "1", "WORLD_SIZE": "1", "RANK": "0"}, "--gpus", "2")
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    r = _run_bench({"VV_BENCH_STUB": "1", "WORLD_SIZE": "2", "RANK": "0"}, "--gpus", "1")
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_under_torchrun_two_ranks():
+    """The driver's own launch line (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2) still works: the
+    ranks take RANK / WORLD_SIZE from torchrun and nobody self-launches."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(VV_BENCH_STUB="1", VV_DIST_BACKEND="gloo")
+    port = 31500 + os.getpid() % 1000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=240, cwd=root)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, r.stdout
