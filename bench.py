@@ -473,10 +473,10 @@ def launch_ranks(n, argv, timeout=None):
     if rc == 0 and not any(ln.strip().startswith(b"{") for ln in lines):
         log("launcher: rank 0 printed no JSON line")
         rc = 1
-    out = sys.stdout if rc == 0 else sys.stderr
-    for ln in lines:
+    for ln in lines:          # stdout carries the result line only; library chatter on rank 0's stdout (gloo's connection notes) goes to stderr
+        out = sys.stdout if rc == 0 and ln.lstrip().startswith(b"{") else sys.stderr
         out.write(ln.decode(errors="replace"))
-    out.flush()
+        out.flush()
     return rc
 
 

@@ -203,11 +203,10 @@ typedef struct vv_head_layer {
   vv_w8 q_gate, q_up, q_down;
 } vv_head_layer;
 
-#define VV_HEAD_CHAIN 1 /* vv_head.flags: run the solver loop as ONE persistent chained kernel instead of one launch per GEMV.  Experimental (vv_chain.hip: spin-wait grid barriers, needs the GPU to itself): honoured only by a library built with -DVV_WITH_CHAIN, ignored by the product build */
 typedef struct vv_head {
   int wdt, D, ffn, layers, latent, cond_dim;
   float eps;
-  int flags;
+  int flags;                 /* reserved, 0 */
   const void* noisy_proj;    /* [D, latent] */
   const void* cond_proj;     /* [D, cond_dim] */
   const void* final_adaln;   /* [2D, D]: shift | scale */

@@ -13,16 +13,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "chain: experimental persistent chained head kernel (needs a VV_WITH_CHAIN=1 build and the GPU to itself)")
-
-
-def pytest_collection_modifyitems(config, items):
-    if os.environ.get("VV_WITH_CHAIN", "0") == "1":
-        return
-    skip = pytest.mark.skip(reason="vv_chain.hip is not in the product build (VV_WITH_CHAIN=1 builds it and enables this test)")
-    for it in items:
-        if "chain" in it.keywords:
-            it.add_marker(skip)
 
 
 def load_golden(name):

@@ -52,39 +52,6 @@ def test_head_sampling_1p5b_vs_oracle(big):
     assert err < 2e-2, f"head sampling 1.5B bf16 vs oracle: rel RMS {err:.3e}"
 
 
-@pytest.mark.chain
-def test_head_chain_kernel_1p5b(big):
-    """The solver loop as ONE persistent chained kernel (vv_chain.hip; experimental, spin-wait grid barriers, needs the GPU to
-    itself).  Not part of the product build nor of the default `-m gpu` run: VV_WITH_CHAIN=1 builds it and enables this test."""
-    from oracle import vv_oracle as O
-    from vibevoice_rocm_amd import _lib as L
-    cfg, sd, m = big
-    eng = m.engine
-    W = _cpu(sd, "model.prediction_head.")
-    g = torch.Generator().manual_seed(1)
-    cond, ncond, noise = torch.randn(1, cfg.hidden, generator=g), torch.randn(1, cfg.hidden, generator=g), torch.randn(1, cfg.latent, generator=g)
-    ref = O.sample_speech_tokens(W, cfg.as_dict(), cond, ncond, noise, 2.0, 20, bf16_t=True)
-
-    def run():
-        with torch.cuda.stream(eng.stream):
-            eng.hidden2[0].copy_(cond[0].cuda()); eng.hidden2[1].copy_(ncond[0].cuda()); eng.noise_dev.copy_(noise[0].cuda())
-            eng.latent.zero_()
-            eng._ck(eng.lib.vv_head_sample(C.byref(eng.w.head), eng.hidden2.data_ptr(), cfg.hidden, eng.noise_dev.data_ptr(), eng.temb.data_ptr(),
-                                           eng._coefs, 20, 2.0, eng.latent.data_ptr(), eng._head_ws.data_ptr(), None, eng.sp), "vv_head_sample")
-        eng.stream.synchronize()
-        return eng.latent.cpu().numpy().copy()
-    per_gemv = run()
-    eng.w.head.flags = L.VV_HEAD_CHAIN
-    try:
-        for _ in range(3):    # replays start from the previous launch's epochs: the tags/flags must be reset per launch
-            chained = run()
-    finally:
-        eng.w.head.flags = 0
-    assert np.isfinite(chained).all()
-    assert rel_rms(chained, per_gemv) < 1e-5
-    assert rel_rms(chained, ref[0].numpy()) < 2e-2
-
-
 def test_llm_prefill_and_batch2_decode_1p5b_vs_oracle(big):
     from oracle import vv_oracle as O
     cfg, sd, m = big

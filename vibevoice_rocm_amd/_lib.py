@@ -16,7 +16,6 @@ VV_F32, VV_BF16, VV_FP8 = 0, 1, 2
 PRO_NONE, PRO_RMSNORM, PRO_SILU = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
 LIN_X_BF16, LIN_OUT_BF16, LIN_W_REUSED = 1, 2, 4
-VV_HEAD_CHAIN = 1           # vv_head.flags: solver loop as one persistent chained kernel (opt-in)
 VV_MAX_STAGES = 8
 
 vp = C.c_void_p

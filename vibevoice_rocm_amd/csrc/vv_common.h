@@ -21,33 +21,8 @@ int vv_set_error(int code, const char* fmt, ...);
   } while (0)
 
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_stream.hip: 1 = launched, 0 = not covered
-int vv_launch_gemv_mfma(const vv_lin_args& a, hipStream_t s);     // vv_gemv_mfma.hip: 1..4 rows on v_mfma 4x4x4; 1 launched, 0 not covered
-int vv_gemv_mfma_init();
-void vv_gemv_mfma_set(int on, int cap);
-void vv_gemv_mfma_set_nopro(int on);
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
 int vv_mfma_gemm_init();
-#ifdef VV_WITH_CHAIN   // experimental persistent chained head kernel (vv_chain.hip): spin-wait grid barriers, needs the GPU to itself.
-                       // Off by default (build with VV_WITH_CHAIN=1); the product library does not contain it.
-int vv_chain_init();                                              // vv_chain.hip
-int vv_launch_head_chain(const vv_head* h, float* const* mod, const float* modf, const float* noise, const vv_dpm_coef* coef, int n_steps,
-                         float cfg_scale, float* latent_out, float* act, float* const* xb, float* const* mb, float* chain_ws,
-                         hipStream_t s);                         // 1 launched, 0 not covered, <0 error
-size_t vv_head_chain_ws_floats(const vv_head* h);
-void vv_chain_set_blocks(int b);
-void vv_chain_set_dbg_mode(int m);
-void vv_chain_set_dbg(int block, int thread);
-void vv_chain_set_head(int on);
-#else
-static inline int vv_chain_init() { return 0; }
-static inline int vv_launch_head_chain(const vv_head*, float* const*, const float*, const float*, const vv_dpm_coef*, int, float, float*, float*,
-                                       float* const*, float* const*, float*, hipStream_t) { return 0; }
-static inline size_t vv_head_chain_ws_floats(const vv_head*) { return 0; }
-static inline void vv_chain_set_blocks(int) {}
-static inline void vv_chain_set_dbg_mode(int) {}
-static inline void vv_chain_set_dbg(int, int) {}
-static inline void vv_chain_set_head(int) {}
-#endif
 // vv_attn_decode.hip: bf16 KV cache, head_dim 128; part / tickets = split-key workspace ([R, heads, nsplit, 130] floats, [R, heads] zeroed ints) or null
 int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float2* rope, const int* lens, float* out,
                           int64_t ldo, float* part, int* tickets, int nsplit, hipStream_t s);

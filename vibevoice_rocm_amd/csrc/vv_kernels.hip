@@ -36,9 +36,7 @@ extern "C" int vv_init(void) {
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
   VV_TRY(vv_convffn_init());
-  VV_TRY(vv_gemv_mfma_init());
-  VV_TRY(vv_fused_init());
-  return vv_chain_init();
+  return vv_fused_init();
 }
 void vv_gemv_stream_set_blocks(int b);
 void vv_gemv_stream_set_opt(int o);
@@ -66,9 +64,6 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "block1d_fused")) { vv_block1d_set_fused(value); return 0; }
   if (key && !strcmp(key, "block1d_blocks")) { vv_block1d_set_blocks(value); return 0; }
   if (key && !strcmp(key, "convffn")) { vv_convffn_set(value); return 0; }
-  if (key && !strcmp(key, "gemv_mfma")) { vv_gemv_mfma_set(value, 0); return 0; }
-  if (key && !strcmp(key, "gemv_mfma_nopro")) { vv_gemv_mfma_set(1, 0); vv_gemv_mfma_set_nopro(value); return 0; }
-  if (key && !strcmp(key, "gemv_mfma_cap")) { vv_gemv_mfma_set(1, value); return 0; }
   if (key && !strcmp(key, "convffn_t1")) { vv_convffn_set_t1(value); return 0; }
   if (key && !strcmp(key, "convffn_t1hs")) { vv_convffn_set_t1hs(value); return 0; }
   if (key && !strcmp(key, "convffn_rows512")) { vv_convffn_set_rows(512, value); return 0; }
@@ -78,10 +73,6 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "skinny")) { vv_skinny_set(value, 0, 0); return 0; }
   if (key && !strcmp(key, "skinny_min_m")) { vv_skinny_set(1, value, 0); return 0; }
   if (key && !strcmp(key, "skinny_max_m")) { vv_skinny_set(1, 0, value); return 0; }
-  if (key && !strcmp(key, "chain_blocks")) { vv_chain_set_blocks(value); return 0; }
-  if (key && !strcmp(key, "chain_dbg_mode")) { vv_chain_set_dbg_mode(value); return 0; }
-  if (key && !strcmp(key, "chain_dbg")) { vv_chain_set_dbg(value >> 16, value & 0xffff); return 0; }
-  if (key && !strcmp(key, "head_chain")) { vv_chain_set_head(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_bk128")) { vv_mfma_set_tiled_bk128(value); return 0; }
   if (key && !strcmp(key, "attn_group")) { g_attn_group = value; return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_k")) { vv_mfma_set_tiled_small_k(value); return 0; }
@@ -516,7 +507,6 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
   if (vv_launch_skinny(a, s)) return 0;                          // a few rows x K = 512..2560, plain epilogue: the resampling convs (vv_convffn.hip)
   if (a.m <= 8) {
-    if (a.m <= 4) { const int rc = vv_launch_gemv_mfma(a, s); if (rc < 0) return rc; if (rc) return 0; }   // bf16 weights, 1..4 rows: matrix-core GEMV
     if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
       // 5..8 rows not covered above: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)

@@ -155,7 +155,6 @@ extern "C" size_t vv_head_ws_bytes(const vv_head* h, int n_steps) {
   const size_t D = h->D;
   return al(8 * D) /*c0*/ + al(R * D) /*c*/ + (size_t)h->layers * al(R * 3 * D) + al(R * 2 * D) + al(8 * D) /*hcur*/ +
          al(8 * (size_t)h->ffn) + al(8 * (size_t)h->latent) /*v*/ + 4 * al(h->latent) /*x, x0 history: double-buffered*/ +
-         al(vv_head_chain_ws_floats(h)) /*flags + tagged hand-off buffers of the chained kernel*/ +
          al(8 * D) /*second hidden-row buffer*/ + 2 * al(D + (size_t)h->latent) /*fused solver state X, M*/;
 }
 
@@ -249,7 +248,6 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   float* v = cv.take(8 * (size_t)h->latent);
   float* xb[2] = {cv.take(h->latent), cv.take(h->latent)};       // x and x0-history are double-buffered per step
   float* mb[2] = {cv.take(h->latent), cv.take(h->latent)};
-  float* chain_ws = cv.take(vv_head_chain_ws_floats(h));
   float* hcur2 = cv.take(8 * (size_t)D);
   float* Xs = cv.take(D + (size_t)h->latent);
   float* Ms = cv.take(D + (size_t)h->latent);
@@ -260,10 +258,6 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   if (cb) VV_TRY(vv_add_rows_silu_bf16(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
   else VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
   VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, cb, stream));
-  // the whole solver loop as one persistent kernel (vv_chain.hip) when the shapes are covered
-  const int chained = sde_noise ? 0 : vv_launch_head_chain(h, mod, modf, noise, coef, n_steps, cfg_scale, latent_out, act, xb, mb, chain_ws, s);
-  if (chained < 0) return chained;
-  if (chained) return 0;
   bool ode = !sde_noise;
   for (int i = 0; i < n_steps && ode; ++i) ode = coef[i].cn == 0.f;          // the SDE solver (variance noise per step) keeps the three-launch boundary
   if (ode && vv_head_boundary_supported(h)) {
