@@ -103,7 +103,8 @@ typedef struct vv_kv {
   int kvdt, layers, rows, kv_heads, s_max, head_dim;
   void* vt;   /* optional transposed value cache [layers][rows][kv_heads][head_dim][s_max] (same dtype): vv_rope_store keeps it in step with v
                  for the rows it stores, and prompt-sized vv_attn calls (bf16, head_dim 128, s_max % 32 == 0) then run both attention products on
-                 the matrix cores without a transpose; NULL: the VALU kernels.  The decode step (vv_attn_decode) neither reads nor writes it. */
+                 the matrix cores without a transpose; NULL: the VALU kernels.  vv_attn_decode appends to it as it appends to v, so a prompt-sized call
+                 at any position after any number of decode steps sees every cached value.  Need not be zero-initialised. */
 } vv_kv;
 
 /* rope_table[R][head_dim/2][2] = {cos, sin}(lens[r] * inv_freq[i]): computed once per step, shared by all layers */
@@ -150,6 +151,9 @@ int vv_copy_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int rows,
  *   order 1: x = cx*x - cd*x0;   order 2: x = cx*x - cd*x0 - 0.5*cd*rinv*(x0 - m_prev);   m_prev = x0 */
 int vv_dpm_step(const float* v, int64_t ldv, int n_samples, int latent, float cfg_scale, float alpha_s, float sigma_s,
                 float cx, float cd, float rinv, int order, float* x, float* m_prev, vv_stream_t stream);
+/* positions after a decode step: lens[0] += 1; token == tok_start: lens[1] = 0 (negative branch refreshed, modeling_vibevoice_inference.py:547-563);
+ * token == tok_diffusion: lens[1] += 1 (the negative step is committed, :575-587), *frame_counter += 1.  tok_start < 0 selects
+ * refresh_negative=False (:501-515): lens[1] += 1 for every token, never reset. */
 int vv_advance_lens(int* lens, const int* token, int tok_start, int tok_diffusion, int* frame_counter, vv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------

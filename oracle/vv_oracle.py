@@ -489,7 +489,7 @@ class GenerateResult:
 def generate(W, cfg: dict, input_ids: List[int], speech_input_mask: Optional[Tensor], speech_embeds: Optional[Tensor],
              special: dict, noise: Tensor, cfg_scale: float = 1.3, n_steps: int = 10, max_length_times: float = 2.0,
              forced_tokens: Optional[List[int]] = None, max_new_tokens: Optional[int] = None,
-             keep_trace: bool = False, bf16_t: bool = False) -> GenerateResult:
+             keep_trace: bool = False, bf16_t: bool = False, refresh_negative: bool = True) -> GenerateResult:
     """Batch-1 restatement of generate().  `special` = dict(speech_start, speech_end, speech_diffusion, eos[, bos]).
     `noise` [F, latent] is consumed one row per diffusion frame (replaces the CPU randn at :699).
     `forced_tokens` overrides the argmax (bench / random-weight runs) but the logits
@@ -497,7 +497,10 @@ def generate(W, cfg: dict, input_ids: List[int], speech_input_mask: Optional[Ten
     embedding the positive branch consumed since the last speech_start; the reference's reset
     (mask all slots, unmask only the next one => position 0, attends to nothing else) is a truncation
     to length 0 — pinned against the reference's own mask surgery by the loop_trace fixture.
-    `bf16_t`: the timestep roundings of the reference's bf16 run (see timestep_embedding)."""
+    `bf16_t`: the timestep roundings of the reference's bf16 run (see timestep_embedding).
+    `refresh_negative=False` (:501-515): the negative branch instead consumes EVERY step's input embedding right after the token
+    choice (a single speech_start at step 0, where inputs_embeds is still None), is never reset on speech_start, and the
+    diffusion branch uses that step's negative hidden state (batch 1: the correction of :588-622 touches no sample)."""
     res = GenerateResult()
     emb = W[LLM + "embed_tokens.weight"]
     ids = list(input_ids)
@@ -530,12 +533,16 @@ def generate(W, cfg: dict, input_ids: List[int], speech_input_mask: Optional[Ten
         if tok == special["speech_end"]:                                           # :540-544
             ac_state.zero()
             sem_state.zero()
-        if not finished and tok == special["speech_start"]:                        # :547-563
+        if not refresh_negative:                                                   # :501-515
+            neg_in = x_in[-1:] if step > 0 else emb[special["speech_start"]].float()[None]
+            nhidden = llm_forward(W, cfg, neg_in, neg_kv, neg_kv.length)[-1]
+        if refresh_negative and not finished and tok == special["speech_start"]:   # :547-563
             neg_kv.truncate(0)
         next_embeds = emb[tok].float()[None]                                       # :567
         if not finished and tok == special["speech_diffusion"]:                    # :571-670
-            neg_in = x_in[-1:] if step > 0 else emb[special["speech_start"]].float()[None]
-            nhidden = llm_forward(W, cfg, neg_in, neg_kv, neg_kv.length)[-1]       # :575-587
+            if refresh_negative:
+                neg_in = x_in[-1:] if step > 0 else emb[special["speech_start"]].float()[None]
+                nhidden = llm_forward(W, cfg, neg_in, neg_kv, neg_kv.length)[-1]   # :575-587
             latent = sample_speech_tokens(W, cfg, hidden[None], nhidden[None], noise[frame][None], cfg_scale,
                                           n_steps, tables, bf16_t=bf16_t)          # :627-631
             scaled = latent / W["model.speech_scaling_factor"].float() - W["model.speech_bias_factor"].float()

@@ -37,7 +37,43 @@ def tiny_weights(tiny_weights_np):
     return {k: torch.from_numpy(v) for k, v in tiny_weights_np.items()}
 
 
-def rel_rms(a, b):
+# ---- parity record: every relative-RMS error a test measures is kept, pass or fail, and written at session end ---------------------
+# ("the measured errors live only in assert messages that print on failure").  On the GPU box the file lands in
+# gpurun_out/ (the only directory that travels back); the copy judged is profiles/r03_parity_errors.json.
+_PARITY = []
+_CURRENT = {"id": None}
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_setup(item):
+    _CURRENT["id"] = item.nodeid
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    out = os.environ.get("VV_PARITY_OUT") or os.path.join(ROOT, "gpurun_out", "r03_parity_errors.json")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        by_test = {}
+        for r in _PARITY:
+            by_test.setdefault(r["test"], []).append({k: v for k, v in r.items() if k != "test"})
+        dev = torch.cuda.get_device_name(0) if torch.cuda.is_available() else "cpu"
+        with open(out, "w") as f:
+            json.dump({"device": dev, "exitstatus": int(exitstatus), "n_measurements": len(_PARITY),
+                       "note": "rel_rms = sqrt(mean((got - ref)^2)) / sqrt(mean(ref^2)); one entry per comparison a test made, in call order",
+                       "tests": by_test}, f, indent=1)
+    except OSError:
+        pass
+
+
+def rel_rms(a, b, what=None):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+    e = float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+    rec = {"test": _CURRENT["id"], "rel_rms": e, "n": int(a.size)}
+    if what:
+        rec["what"] = str(what)
+    _PARITY.append(rec)
+    return e

@@ -5,6 +5,7 @@ import os
 import re
 import sys
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -223,6 +224,77 @@ def test_streamer_threaded():
     assert st.audio_queues[0].empty()
     st.end()
     assert st.finished_flags == [True, True]
+
+
+def test_streamer_batch_iterator_threaded():
+    """`for d in streamer`: {sample: chunk} dicts until every sample has ended (reference streamer.py:107-147), producer on another thread."""
+    from vibevoice_rocm_amd.streamer import AudioStreamer
+    st = AudioStreamer(batch_size=3, timeout=5)
+
+    def produce():
+        for i in range(4):
+            st.put(torch.full((2, 1, 4), float(i)), torch.tensor([0, 2]))
+            if i == 1:
+                st.end(torch.tensor([2]))
+        st.end()
+
+    th = threading.Thread(target=produce)
+    th.start()
+    seen = {0: [], 1: [], 2: []}
+    for d in st:
+        for k, v in d.items():
+            seen[k].append(float(v.mean()))
+    th.join(5)
+    assert seen == {0: [0.0, 1.0, 2.0, 3.0], 1: [], 2: [0.0, 1.0]}
+    with pytest.raises(ValueError):
+        st.get_stream(3)
+
+
+def test_async_streamer_from_generating_thread():
+    """AsyncAudioStreamer (reference streamer.py:150-264): queues live on the consumer's event loop, put()/end() come from the
+    generating thread; per-sample `async for` and the batch `async for` both see every chunk in order, nothing after end()."""
+    import asyncio
+    from vibevoice_rocm_amd.streamer import AsyncAudioStreamer
+
+    async def main():
+        st = AsyncAudioStreamer(batch_size=2, timeout=5)
+
+        def produce():
+            for i in range(5):
+                st.put(torch.full((2, 1, 8), float(i)), torch.tensor([0, 1]))
+                time.sleep(0.002)
+            st.end(torch.tensor([1]))
+            st.put(torch.full((2, 1, 8), 9.0), torch.tensor([0, 1]))      # sample 1 has ended: only sample 0 receives this
+            st.end()
+
+        th = threading.Thread(target=produce)
+        th.start()
+
+        async def one(i):
+            return [float(c.mean()) async for c in st.get_stream(i)]
+        a, b = await asyncio.gather(one(0), one(1))
+        th.join(5)
+        assert a == [0.0, 1.0, 2.0, 3.0, 4.0, 9.0] and b == [0.0, 1.0, 2.0, 3.0, 4.0]
+        assert st.finished_flags == [True, True]
+
+        st2 = AsyncAudioStreamer(batch_size=3, timeout=5)
+
+        def produce2():
+            for i in range(6):
+                st2.put(torch.full((1, 1, 8), float(i)), torch.tensor([i % 3]))
+            st2.end()
+        th2 = threading.Thread(target=produce2)
+        th2.start()
+        got = {0: [], 1: [], 2: []}
+        async for d in st2:
+            for k, v in d.items():
+                got[k].append(float(v.mean()))
+        th2.join(5)
+        assert got == {0: [0.0, 3.0], 1: [1.0, 4.0], 2: [2.0, 5.0]}
+        with pytest.raises(ValueError):
+            async for _ in st2.get_stream(5):
+                pass
+    asyncio.run(main())
 
 
 def _dist_worker(rank, world, port, q, bcast="broadcast"):

@@ -188,6 +188,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
       pv.z = bf16_bits(vn[4]) | (bf16_bits(vn[5]) << 16); pv.w = bf16_bits(vn[6]) | (bf16_bits(vn[7]) << 16);
       *reinterpret_cast<att_raw*>(kc + (int64_t)pos * d + e0) = pk;
       *reinterpret_cast<att_raw*>(vc + (int64_t)pos * d + e0) = pv;
+      if (kv.vt) {                               // the transposed copy the matrix-core prompt attention reads stays in step with v
+        bf16_t* vtc = reinterpret_cast<bf16_t*>(kv.vt) + base + pos;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) vtc[(int64_t)(e0 + j) * kv.s_max] = (bf16_t)bf16_bits(vn[j]);
+      }
     }
   }
   ASTAMP(3);                                       // new token + append

@@ -46,15 +46,10 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
   const int q0 = qt * 32;
   const int qrow = min(q0 + r, R - 1);                    // rows past R repeat the last row (never stored)
   const int len_q = lens[qrow];
-  const int crow = cache_rows ? cache_rows[min(q0, R - 1)] : min(q0, R - 1);
-  // number of keys any query of the tile may see: max(len) + 1 over the tile
-  int kmax = len_q + 1;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o));
-  const int n_tiles = (kmax + 31) >> 5;
-  const int64_t base = ((((int64_t)layer * kv.rows + crow) * kv.kv_heads + kvh) * kv.s_max) * d;
-  const bf16_t* kc = reinterpret_cast<const bf16_t*>(kv.k) + base;          // [s_max][d]
-  const bf16_t* vt = reinterpret_cast<const bf16_t*>(kv.vt) + base;         // [d][s_max]
+  // cache row of THIS lane's query (vv_hip.h: cache_rows[r], NULL = r).  A tile's K / V operands come from one cache row, so a tile whose
+  // queries name several rows runs once per distinct row: the lanes of the other rows ride along (finite garbage on their own accumulator
+  // columns only: an MFMA output column depends on its own B column) and store nothing.  A prompt prefill has one row per call: one pass.
+  const int my_crow = cache_rows ? cache_rows[qrow] : qrow;
   // Q^T fragments of the tile: B operand of k-step s holds Q[q0 + r][16 s + 8 h + j], scaled into the log2 domain
   const float qsc = rsqrtf((float)d) * 1.4426950408889634f;
   const float* qp = qkv + (int64_t)qrow * ld + head * d + 8 * h;
@@ -66,6 +61,19 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
     p.x = pk2(a.x * qsc, a.y * qsc); p.y = pk2(a.z * qsc, a.w * qsc); p.z = pk2(b.x * qsc, b.y * qsc); p.w = pk2(b.z * qsc, b.w * qsc);
     qf[s] = as_frag(p);
   }
+  unsigned long long todo = __ballot(1);
+  while (todo) {
+  const int crow = __builtin_amdgcn_readlane(my_crow, __ffsll((long long)todo) - 1);
+  const bool mine = my_crow == crow;
+  todo &= ~__ballot(mine);
+  // number of keys any query of this pass may see: max(len) + 1 over its lanes
+  int kmax = mine ? len_q + 1 : 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o));
+  const int n_tiles = (kmax + 31) >> 5;
+  const int64_t base = ((((int64_t)layer * kv.rows + crow) * kv.kv_heads + kvh) * kv.s_max) * d;
+  const bf16_t* kc = reinterpret_cast<const bf16_t*>(kv.k) + base;          // [s_max][d]
+  const bf16_t* vt = reinterpret_cast<const bf16_t*>(kv.vt) + base;         // [d][s_max]
   f32x16 oacc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -89,6 +97,20 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
         vf[dt][s][0] = *reinterpret_cast<const u32x2*>(vp + 16 * s);
         vf[dt][s][1] = *reinterpret_cast<const u32x2*>(vp + 16 * s + 8);
       }
+    }
+    if (t + 1 == n_tiles) {
+      // slots past the last visible key carry P = 0, but 0 x NaN is NaN: whatever bit patterns the cache holds behind the position
+      // (vv_kv.vt need not be zero-initialised) are scrubbed from the value fragments of the last tile
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const int left = kmax - (key0 + 16 * s + 8 * x + 4 * h);       // visible keys among this fragment's 4
+          const unsigned m0 = left >= 2 ? 0xffffffffu : (left == 1 ? 0x0000ffffu : 0u);
+          const unsigned m1 = left >= 4 ? 0xffffffffu : (left == 3 ? 0x0000ffffu : 0u);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) { vf[dt][s][x].x &= m0; vf[dt][s][x].y &= m1; }
+        }
     }
     if (t + 1 < n_tiles) {
 #pragma unroll
@@ -143,7 +165,7 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
   }
   const float l_tot = l_half + __shfl_xor(l_half, 32);
   const float inv = 1.0f / l_tot;
-  if (q0 + r < R) {
+  if (mine && q0 + r < R) {
     float* op = out + (int64_t)(q0 + r) * ldo + head * d + 4 * h;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -152,6 +174,7 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
         *reinterpret_cast<float4*>(op + dt * 32 + 8 * g) =
             make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
       }
+  }
   }
 }
 

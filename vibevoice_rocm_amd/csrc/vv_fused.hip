@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void llm_tail_kernel(const float* h, int64_t l
     *token_out = t;
     if (lens) {
       lens[0] += 1;
-      if (t == tok_start) lens[1] = 0;
+      if (tok_start < 0) { lens[1] += 1; if (t == tok_diff && frame_ctr) *frame_ctr += 1; }      // refresh_negative=False: the negative row consumes every token
+      else if (t == tok_start) lens[1] = 0;
       else if (t == tok_diff) { lens[1] += 1; if (frame_ctr) *frame_ctr += 1; }
     }
   }
@@ -319,7 +320,8 @@ __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int6
     *token_out = t;
     if (lens) {
       lens[0] = l0 + 1;
-      if (t == tok_start) lens[1] = 0;
+      if (tok_start < 0) { lens[1] = l1 + 1; if (t == tok_diff && frame_ctr) *frame_ctr = fc + 1; }   // refresh_negative=False: the negative row consumes every token
+      else if (t == tok_start) lens[1] = 0;
       else if (t == tok_diff) { lens[1] = l1 + 1; if (frame_ctr) *frame_ctr = fc + 1; }
     }
   }

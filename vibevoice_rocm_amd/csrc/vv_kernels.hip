@@ -1618,12 +1618,14 @@ extern "C" int vv_dpm_proj(const float* v, int64_t ldv, float cfg_scale, const v
 }
 
 // device-side bookkeeping so a whole frame can be replayed as one graph:
-// lens[0] (positive position) += 1; token == tok_start -> lens[1] = 0; token == tok_diffusion -> lens[1] += 1, frame += 1
+// lens[0] (positive position) += 1; token == tok_start -> lens[1] = 0; token == tok_diffusion -> lens[1] += 1, frame += 1;
+// tok_start < 0: lens[1] += 1 for every token (the negative branch is never refreshed)
 __global__ void advance_lens_kernel(int* lens, const int* token, int tok_start, int tok_diff, int* frame) {
   if (threadIdx.x == 0) {
     const int t = *token;
     lens[0] += 1;
-    if (t == tok_start) lens[1] = 0;
+    if (tok_start < 0) { lens[1] += 1; if (t == tok_diff && frame) *frame += 1; }   // refresh_negative=False (modeling_vibevoice_inference.py:501-515)
+    else if (t == tok_start) lens[1] = 0;
     else if (t == tok_diff) { lens[1] += 1; if (frame) *frame += 1; }
   }
 }

@@ -352,6 +352,7 @@ static size_t convnet_pad_floats(const vv_convnet* net, int64_t t_in, size_t* of
 // scratch histories of the one-row stage's blocks (<= 16 blocks x 6 rows x 2048 channels), see run_blocks
 #define VV_ROW_BLOCKS 16
 #define VV_ROW_HIST_FLOATS ((size_t)VV_ROW_BLOCKS * 6 * 2048)
+#define VV_CTX_ITEMS (VV_MAX_STAGES + 1 + 2 * VV_ROW_BLOCKS)   // capacity of a net's streaming-state move list
 
 extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int decoder) {
   if (!net || t_in <= 0) return 0;
@@ -366,7 +367,7 @@ extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int d
 // other row tiles already write): the result must not overlap the input; `other` is free (no mixer output) and takes it.
 static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*& cur, float*& other, float* hid,
                       int nctx, float** pad_out, vv_stream_t stream, float* next_pad = nullptr, float* row_hist = nullptr,
-                      vv_conv_ctx_item* items = nullptr, int* n_items = nullptr) {
+                      vv_conv_ctx_item* items = nullptr, int* n_items = nullptr, int* row_stage = nullptr) {
   // row_hist / items (streaming nets): scratch for the new histories of the one-row stage's blocks and the list of state moves that the
   // net's closing vv_conv_ctx_batch performs (a block's history may only be replaced once every workgroup that reads it is done)
   // next_pad (streaming nets): the next conv's own padded-input region; the stage result goes to next_pad + nctx rows
@@ -386,13 +387,17 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
     }
     float* final_dst = last ? (next_pad ? next_pad : cur) + (size_t)nctx * C : nullptr;
     if (last) *pad_out = next_pad ? next_pad : cur;
-    if (T == 1 && row_hist && items && n_items && j < VV_ROW_BLOCKS && B.hist && !B.q_w1.q) {
+    // one-row fast path: row_hist holds one scratch history per block index j, so only ONE stage of a net may take it (the shipped nets
+    // have a single T == 1 stage; a second one falls through to the general path below), and the item list must have room
+    if (T == 1 && row_hist && items && n_items && j < VV_ROW_BLOCKS && B.hist && !B.q_w1.q && *n_items < VV_CTX_ITEMS &&
+        (*row_stage < 0 || *row_stage == stage)) {
       // the one-row stage (C = 2048): mixer + RMSNorm + first GEMM + GELU as one launch (vv_convffn.hip), then the weight-streaming GEMV
       float* hn = row_hist + (size_t)j * 6 * C;
       int one = vv_launch_ffn_in_row_hs(B, net->wdt, cur, other, hid, hn, C, net->eps, (hipStream_t)stream);
       if (one == 0) one = vv_launch_ffn_in_row(B, net->wdt, cur, other, hid, hn, C, net->eps, (hipStream_t)stream);
       if (one < 0) return one;
       if (one) {
+        *row_stage = stage;
         items[(*n_items)++] = vv_conv_ctx_item{hn, B.hist, 6, 0, C, B.dw_w, B.hs};   // the scatter also refreshes hs from the rows it stores
         float* dst1 = (last && final_dst) ? final_dst : other;
         vv_lin_args a1 = lin_base(hid, 4 * C, 1, B.w2, C, 4 * C, net->wdt, dst1, C);
@@ -404,8 +409,10 @@ static int run_blocks(const vv_convnet* net, int stage, int64_t T, int C, float*
         continue;
       }
     }
-    if (B.hs && B.hist && items && n_items && *n_items < VV_MAX_STAGES + 1 + VV_ROW_BLOCKS)
+    if (B.hs && B.hist && items && n_items) {
+      if (*n_items >= VV_CTX_ITEMS) return vv_set_error(VV_E_UNSUPPORTED, "convnet: more than %d streaming-state moves in one net", VV_CTX_ITEMS);
       items[(*n_items)++] = vv_conv_ctx_item{B.hist, B.hist, 6, 0, C, B.dw_w, B.hs};   // this block's history changes below on a general path: hs follows at the closing scatter
+    }
     {   // middle stages of a streaming frame (C = 256 / 512): mixer + first GEMM, second GEMM (vv_convffn.hip); the bf16 hidden tile
         // fills the first half of `hid`, the scratch history sits behind it
       float* dst2 = (last && final_dst) ? final_dst : other;
@@ -480,8 +487,8 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
   const bool streaming = convnet_streaming(net);
   size_t poff[VV_MAX_STAGES + 1];
   float* pads = nullptr;
-  vv_conv_ctx_item items[VV_MAX_STAGES + 1 + VV_ROW_BLOCKS];
-  int n_items = 0;
+  vv_conv_ctx_item items[VV_CTX_ITEMS];
+  int n_items = 0, row_stage = -1;
   float* row_hist = nullptr;
   if (streaming) {
     pads = cvr.take(convnet_pad_floats(net, T0, poff));
@@ -528,7 +535,7 @@ extern "C" int vv_decoder_forward(const vv_convnet* net, const float* latent, in
       // the last block writes straight into the next conv's padded input; which buffer that is depends on block parity:
       // block j reads cur -> writes other, then they swap.  The last block's mixer output sits in `other_last`, its
       // result may go anywhere except that buffer and hid: use the buffer holding the (dead) input of that block.
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad, row_hist, items, &n_items));
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad, row_hist, items, &n_items, &row_stage));
     } else {
       float* dstb = next_pad ? next_pad : other;
       hipError_t e = hipMemcpyAsync(dstb + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
@@ -566,8 +573,8 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
   }
   size_t poff[VV_MAX_STAGES + 1];
   float* pads = nullptr;
-  vv_conv_ctx_item items[VV_MAX_STAGES + 1 + VV_ROW_BLOCKS];
-  int n_items = 0;
+  vv_conv_ctx_item items[VV_CTX_ITEMS];
+  int n_items = 0, row_stage = -1;
   float* row_hist = nullptr;
   if (streaming) {
     pads = cvr.take(convnet_pad_floats(net, T0, poff));
@@ -633,7 +640,7 @@ extern "C" int vv_encoder_forward(const vv_convnet* net, const float* wav, int64
     const int nctx = conv_ctx_of(nxt);
     float* next_pad = streaming ? pads + poff[i + 1] : nullptr;
     if (net->n_blocks[i] > 0) {
-      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad, row_hist, items, &n_items));
+      VV_TRY(run_blocks(net, i, T, C, cur, other, hid, nctx, &pad, stream, next_pad, row_hist, items, &n_items, &row_stage));
     } else {
       float* dstb = next_pad ? next_pad : other;
       e = hipMemcpyAsync(dstb + (size_t)nctx * C, cur, (size_t)T * C * 4, hipMemcpyDeviceToDevice, s);

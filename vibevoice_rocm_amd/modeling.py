@@ -144,7 +144,6 @@ class VibeVoiceForConditionalGenerationInference:
         self.device = self.engine.device
         # batches run in lock step on one Engine per sample (own HIP stream, KV cache and conv state; matrices already in the streamed
         # dtype on the device are shared, not copied): lanes beyond the first are built on first use from this state dict
-        self._state_dict = state_dict
         self._lanes = [self.engine]
         self._use_graphs = use_graphs
         self.ddpm_inference_steps = config.ddpm_infer
@@ -255,9 +254,7 @@ class VibeVoiceForConditionalGenerationInference:
         sample_fn = _make_sampler(gen_cfg) if gen_cfg.get("do_sample", False) else None
         verbose = kwargs.get("verbose", False)
         max_length_times = kwargs.get("max_length_times", 2)
-        refresh_negative = kwargs.get("refresh_negative", True)
-        if not refresh_negative:
-            raise NotImplementedError("refresh_negative=False is not built (every reference caller passes True / default)")
+        refresh_negative = bool(kwargs.get("refresh_negative", True))     # False: reference :501-515 (no caller of the reference uses it)
         self._prefill_chunk = int(kwargs.get("prefill_chunk", 1024))   # extension: rows per prefill launch sequence (cfg 5: 512-token chunks)
         forced_tokens = kwargs.get("forced_tokens")          # extension: bench / fixtures drive the token schedule
         noise = kwargs.get("noise")                          # extension: injected diffusion noise [F, latent]
@@ -280,6 +277,10 @@ class VibeVoiceForConditionalGenerationInference:
             sn = speech_noise or (None, None)
             _, conn_all = self._process_speech_inputs(torch.as_tensor(speech_tensors).float(), torch.as_tensor(speech_masks).bool(), *sn)
         if B > 1:
+            if not refresh_negative:
+                # with refresh_negative=False the reference's batched loop couples the samples (a non-diffusing sample's negative step is
+                # dropped only in steps where some OTHER sample diffuses, :588-622): served per sample here would not reproduce that
+                raise NotImplementedError("refresh_negative=False is built for batch size 1 only")
             return self._generate_lockstep(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
                                            forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
                                            audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev)
@@ -298,7 +299,7 @@ class VibeVoiceForConditionalGenerationInference:
                     off += n_b
             r = self._generate_one(ids_b, sp_b, conn_b, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
                                    None if noise is None else torch.as_tensor(noise), audio_streamer, stop_check_fn, b, verbose, sample_fn,
-                                   None if sde_noise is None else torch.as_tensor(sde_noise))
+                                   None if sde_noise is None else torch.as_tensor(sde_noise), refresh_negative=refresh_negative)
             seqs.append(torch.cat([input_ids[b][~keep], r["sequence"]]))
             audios.append(r["audio"])
             reach.append(r["reach_max"])
@@ -319,7 +320,7 @@ class VibeVoiceForConditionalGenerationInference:
     def _lane(self, b: int) -> Engine:
         while len(self._lanes) <= b:
             n = len(self._lanes)             # lanes past LANES_IN_FLIGHT share the stream of lane n % LANES_IN_FLIGHT: see _generate_lockstep
-            eng = Engine(self.config, self._state_dict, device=self.device, dtype=self.dtype, use_graphs=self._use_graphs, weight_quant=self.weight_quant,
+            eng = Engine(self.config, None, device=self.device, dtype=self.dtype, use_graphs=self._use_graphs, weight_quant=self.weight_quant,
                          stream=self._lanes[n % LANES_IN_FLIGHT].stream if n >= LANES_IN_FLIGHT else None, weights_from=self.engine)
             eng.scheduler = self.engine.scheduler
             self._lanes.append(eng)
@@ -528,7 +529,7 @@ class VibeVoiceForConditionalGenerationInference:
                                          reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
 
     def _generate_one(self, ids: torch.Tensor, sp_mask, conn, special, cfg_scale, max_new_tokens, max_length_times, forced_tokens,
-                      noise, audio_streamer, stop_check_fn, sample_idx, verbose, sample_fn=None, sde_noise=None):
+                      noise, audio_streamer, stop_check_fn, sample_idx, verbose, sample_fn=None, sde_noise=None, refresh_negative=True):
         eng, cfg = self.engine, self.config
 
         def draw(frame):
@@ -542,6 +543,9 @@ class VibeVoiceForConditionalGenerationInference:
 
         ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
         valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
+        # device-side position bookkeeping (vv_advance_lens): a negative "speech_start" id selects refresh_negative=False - the negative
+        # row consumes every step's embedding and is never reset (:501-515); the batch-2 step computes that row anyway
+        ST_dev = ST if refresh_negative else -1
         L0 = int(ids.shape[0])
         max_length = cfg.max_pos if max_new_tokens is None else L0 + int(max_new_tokens)          # :370-371
         max_steps = min(max_length - L0, int(max_length_times * L0))                            # :420
@@ -585,8 +589,8 @@ class VibeVoiceForConditionalGenerationInference:
             speculated = False
             if step == 0:
                 eng.prefill(x0, row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024))
-                tok = eng.first_token(ST, SD, forced, sample_fn)
-                if tok == SD:
+                tok = eng.first_token(ST_dev, SD, forced, sample_fn)
+                if tok == SD or not refresh_negative:
                     # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
                     eng.prefill(eng.embed_ids(torch.tensor([ST])), row=1, pos0=0)
             elif speculate and prev_tok == SD and (pending_nz is not None or ((noise is None or frame < len(noise)) and
@@ -596,12 +600,12 @@ class VibeVoiceForConditionalGenerationInference:
                 # made for a mis-speculated frame is kept for the next real one (same RNG sequence).
                 if pending_nz is None:
                     pending_nz = draw(frame)
-                tok = eng.step_decode_speculative(ST, SD, forced, *pending_nz, on_enqueued=hook)
+                tok = eng.step_decode_speculative(ST_dev, SD, forced, *pending_nz, on_enqueued=hook)
                 speculated = True
                 if tok != SD:
                     eng.rollback_speech_state()
             else:
-                tok = eng.step_decode(ST, SD, forced, sample_fn, on_enqueued=hook)              # :478-496 (+ speculative :581-583)
+                tok = eng.step_decode(ST_dev, SD, forced, sample_fn, on_enqueued=hook)          # :478-496 (+ speculative :581-583)
             prev_tok = tok
             seq.append(tok)
             if tok == EOS:                                                                      # :517-526
