@@ -455,3 +455,82 @@ def test_prefill_at_pos0_after_decode_steps_vs_oracle():
     err = rel_rms(got.numpy(), want.numpy(), "prefill at pos0=25 after 5 decode steps (mid, bf16) vs oracle")
     assert err < 2e-2, f"prefill after decode steps: rel RMS {err:.3e}"
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# grouped-query decode attention on the matrix cores (vv_attn_decode.hip)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("heads,kv_heads,lens,s_max", [(12, 2, (370, 41), 640), (12, 2, (0, 0), 64), (28, 4, (513, 1), 1024), (4, 2, (31, 32), 64),
+                                                       (12, 2, (1023, 600), 1024), (16, 2, (100, 7), 128)])
+def test_decode_attention_gqa_vs_torch(heads, kv_heads, lens, s_max):
+    """vv_attn_decode (RoPE on q and the new k, KV append, GQA attention over 0..lens[r] for the rows {positive, negative}; Qwen2 attention
+    under modeling_vibevoice.py:187-199, call sites modeling_vibevoice_inference.py:478-480,581-583) on a bf16 cache with a transposed
+    value copy: the grouped kernel (one workgroup per (row, KV head), all q heads of the group on one K / V pass, matrix cores with
+    hi + lo split operands) against torch fp32 on the same cache contents, AND against the per-head VALU kernel (vv_tune attn_gqa 0);
+    the appended k / v / v^T slots must hold the rotated key and the value.  Cache slots behind the position are NaN-filled."""
+    _need_gpu()
+    from vibevoice_rocm_amd import _lib as L
+    l = L.load()
+    g = torch.Generator().manual_seed(heads + sum(lens))
+    d, layers, rows, layer, R = 128, 2, 2, 1, 2
+    G = heads // kv_heads
+    kc = torch.randn(layers, rows, kv_heads, s_max, d, generator=g).to(torch.bfloat16)
+    vc = torch.randn(layers, rows, kv_heads, s_max, d, generator=g).to(torch.bfloat16)
+    nan = torch.tensor(float("nan"), dtype=torch.bfloat16)
+    for r in range(R):
+        kc[:, r, :, lens[r]:] = nan
+        vc[:, r, :, lens[r]:] = nan
+    ld = (heads + 2 * kv_heads) * d
+    qkv = torch.randn(R, ld, generator=g)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    inv_freq = 1.0 / (1e6 ** (torch.arange(0, d, 2, dtype=torch.float32) / d))
+
+    def run(gqa):
+        kd, vd = kc.cuda(), vc.cuda()
+        vtd = vc.transpose(-1, -2).contiguous().cuda()
+        qd, ld_, fd = qkv.cuda(), lens_t.cuda(), inv_freq.cuda()
+        rope = torch.empty(R, d // 2, 2, device="cuda")
+        out = torch.full((R, heads * d), float("nan"), device="cuda")
+        kv = L.KV(kd.data_ptr(), vd.data_ptr(), L.VV_BF16, layers, rows, kv_heads, s_max, d, vtd.data_ptr())
+        l.vv_tune(b"attn_gqa", gqa)
+        try:
+            L.check(l.vv_rope_table(ld_.data_ptr(), fd.data_ptr(), R, d, rope.data_ptr(), None), "vv_rope_table")
+            L.check(l.vv_attn_decode(qd.data_ptr(), ld, R, heads, C.byref(kv), layer, rope.data_ptr(), ld_.data_ptr(), out.data_ptr(), heads * d, None), "vv_attn_decode")
+            torch.cuda.synchronize()
+        finally:
+            l.vv_tune(b"attn_gqa", 1)
+        return out.cpu(), kd.cpu(), vd.cpu(), vtd.cpu()
+
+    def rot(x, pos):
+        ang = pos * inv_freq
+        c, s_ = torch.cos(ang), torch.sin(ang)
+        x1, x2 = x[..., : d // 2], x[..., d // 2:]
+        return torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], -1)
+
+    want = torch.empty(R, heads, d)
+    knew, vnew = [], []
+    for r in range(R):
+        q = rot(qkv[r, : heads * d].view(heads, d), float(lens[r]))
+        kn = rot(qkv[r, heads * d: (heads + kv_heads) * d].view(kv_heads, d), float(lens[r]))
+        vn = qkv[r, (heads + kv_heads) * d:].view(kv_heads, d)
+        knew.append(kn); vnew.append(vn)
+        for h in range(heads):
+            kh = torch.cat([kc[layer, r, h // G, : lens[r]].float(), kn[h // G][None]])
+            vh = torch.cat([vc[layer, r, h // G, : lens[r]].float(), vn[h // G][None]])
+            want[r, h] = torch.softmax((q[h] @ kh.T) / d ** 0.5, -1) @ vh
+    got, k2, v2, vt2 = run(1)
+    assert bool(torch.isfinite(got).all())
+    e = rel_rms(got.numpy(), want.reshape(R, -1).numpy(), f"grouped decode attention heads={heads}/{kv_heads} lens={lens}")
+    assert e < 2e-4, f"grouped decode attention vs torch: rel RMS {e:.3e}"
+    for r in range(R):
+        ek = rel_rms(k2[layer, r, :, lens[r]].float().numpy(), knew[r].numpy())
+        ev = rel_rms(v2[layer, r, :, lens[r]].float().numpy(), vnew[r].numpy())
+        evt = rel_rms(vt2[layer, r, :, :, lens[r]].float().numpy(), vnew[r].numpy())
+        assert ek < 4e-3 and ev < 4e-3 and evt < 4e-3, f"appended slot row {r}: k {ek:.2e} v {ev:.2e} v^T {evt:.2e} (bf16 rounding only)"
+        assert torch.equal(v2[layer, r, :, lens[r]], vt2[layer, r, :, :, lens[r]])
+    old, k1, v1, vt1 = run(0)
+    e_old = rel_rms(old.numpy(), want.reshape(R, -1).numpy(), "per-head decode attention, same inputs")
+    assert e_old < 2e-4
+    for r in range(R):       # both kernels append the same bits
+        assert torch.equal(k1[layer, r, :, lens[r]], k2[layer, r, :, lens[r]]) and torch.equal(v1[layer, r, :, lens[r]], v2[layer, r, :, lens[r]])
+        assert torch.equal(vt1[layer, r, :, :, lens[r]], vt2[layer, r, :, :, lens[r]])

@@ -253,6 +253,283 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Grouped-query decode attention on the matrix cores: ONE workgroup per (row, KV head[, key split]) serves all G = heads / kv_heads q heads of
+// the group from a single pass over K / V (the per-head kernel above gives every q head its own workgroup on consecutive block ids: six XCD
+// L2s each fetch the same K / V - 3.06 MB fetched per launch for 0.4 MB of cache at S = 370, rocprofv3 FETCH_SIZE, r02).
+//   scores   S^T[key, q] = K[key, :] . Q[q, :]     v_mfma_f32_16x16x32_bf16: A = 16 keys x 32 d straight from the key-major cache (one 16-B
+//                                                  load per lane), B = Q^T: lane (n = lane & 15, g = lane >> 4) holds d = 32 s + 8 g .. + 8 of
+//                                                  q head n, RoPE applied in registers, split into bf16 hi + lo parts (fp32-grade products);
+//                                                  queries n >= G are zero columns
+//   softmax  the accumulator has the query on the lane: lane (n, g) holds keys 4 g + {0..3} of each 16-key tile; running maximum per query
+//            (two cross-row exchanges per 32 keys), sum kept per lane and folded once at the end; log2 domain
+//   output   O^T[d, q] += V^T[d, key] . P[key, q]  A = V^T from the transposed value cache vv_kv.vt (two 8-B loads per 16 d x 32 keys), B = P
+//                                                  straight from the score registers (key slot 8 g + j of the 32-deep step = the lane's own
+//                                                  eight scores), again as bf16 hi + lo
+// Each of the NW waves walks 32-key tiles wave, wave + NW, ...; the waves' (m, l, O) meet in LDS once.  The new token's score and value come
+// from the projection registers; the workgroup of split 0 appends k (rotated), v and the transposed v at slot pos.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 gq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gq_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gq_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned gq_pk(float a, float b) { return bf16_bits(a) | (bf16_bits(b) << 16); }
+__device__ __forceinline__ float gq_bf_round(float a) { return __uint_as_float(bf16_bits(a) << 16); }
+__device__ __forceinline__ gq_bf16x8 gq_frag(att_raw v) { return __builtin_bit_cast(gq_bf16x8, v); }
+// split 8 floats into bf16 hi and lo fragments: hi + lo reproduces the fp32 value to 2^-17 relative
+__device__ __forceinline__ void gq_split(const float (&x)[8], att_raw& hi, att_raw& lo) {
+  float h[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { h[j] = gq_bf_round(x[j]); l[j] = x[j] - h[j]; }
+  hi.x = gq_pk(h[0], h[1]); hi.y = gq_pk(h[2], h[3]); hi.z = gq_pk(h[4], h[5]); hi.w = gq_pk(h[6], h[7]);
+  lo.x = gq_pk(l[0], l[1]); lo.y = gq_pk(l[2], l[3]); lo.z = gq_pk(l[4], l[5]); lo.w = gq_pk(l[6], l[7]);
+}
+
+constexpr int GQ_MAXG = 8;      // q heads per KV head covered (1.5B: 6, 7B: 7)
+constexpr int GQ_PITCH = 132;   // floats per (wave, query) row of the merge buffer
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* qkv, int64_t ld, int heads, vv_kv kv, int layer, const float2* rope, const int* lens,
+                                                                 float* out, int64_t ldo, float* part, int* tickets) {
+  constexpr int d = 128;
+  __shared__ __attribute__((aligned(16))) float so[NW][GQ_MAXG][GQ_PITCH];     // per wave and query: O[128], then m, l
+  __shared__ float s_new[GQ_MAXG];
+  __shared__ int s_last;
+  const int kvh = blockIdx.x, r = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int G = heads / kv.kv_heads;
+  const int nq = n < G ? n : G - 1;                      // lanes of the unused query columns read head G - 1 (zeroed below)
+  const float* row = qkv + (int64_t)r * ld;
+  const int64_t base = ((((int64_t)layer * kv.rows + r) * kv.kv_heads + kvh) * kv.s_max) * d;
+  bf16_t* kc = reinterpret_cast<bf16_t*>(kv.k) + base;
+  bf16_t* vc = reinterpret_cast<bf16_t*>(kv.v) + base;
+  bf16_t* vt = reinterpret_cast<bf16_t*>(kv.vt) + base;   // [d][s_max]
+  // ---- requests: q chunks of this lane's head, the new k chunks, RoPE table, and (unsplit contexts) the first two key tiles -------------
+  const float* qp = row + (int64_t)(kvh * G + nq) * d + 8 * g;
+  const float* kp = row + (int64_t)(heads + kvh) * d + 8 * g;
+  float4 qr[4][2], kr[4][2], rr[2][4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    qr[s][0] = *reinterpret_cast<const float4*>(qp + 32 * s); qr[s][1] = *reinterpret_cast<const float4*>(qp + 32 * s + 4);
+    kr[s][0] = *reinterpret_cast<const float4*>(kp + 32 * s); kr[s][1] = *reinterpret_cast<const float4*>(kp + 32 * s + 4);
+  }
+  const float2* rp = rope + (int64_t)r * 64 + 8 * g;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rr[s][i] = *reinterpret_cast<const float4*>(rp + 32 * s + 2 * i);     // {cos, sin} x 2 per float4
+  att_raw kraw[2][2][4];            // [buffer][16-key tile][k-step]
+  gq_u32x2 vraw[2][8][2];           // [buffer][d tile][16-key tile]
+  auto issue = [&](int buf, int key0, int kmax_valid) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int key = min(key0 + 16 * t + n, kmax_valid);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kraw[buf][t][s] = *reinterpret_cast<const att_raw*>(kc + (int64_t)key * d + 32 * s + 8 * g);
+    }
+    const int kb = min(key0, kv.s_max - 32) + 4 * g;                  // 8-B fragments never leave the row: s_max % 32 == 0
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16_t* vp = vt + (int64_t)(dt * 16 + n) * kv.s_max + kb;
+      vraw[buf][dt][0] = *reinterpret_cast<const gq_u32x2*>(vp);
+      vraw[buf][dt][1] = *reinterpret_cast<const gq_u32x2*>(vp + 16);
+    }
+  };
+  const bool spec = nsplit == 1;     // unsplit: the first tiles are requested before the position is known (masked / scrubbed when consumed)
+  if (spec) issue(0, 32 * wave, kv.s_max - 1);
+  const int pos = lens[r];
+  const int per = ((pos + nsplit - 1) / nsplit + 31) & ~31;          // keys per split, whole tiles
+  const int ks = split * per, ke = min(pos, ks + per);
+  if (!spec) issue(0, ks + 32 * wave, kv.s_max - 1);
+  // ---- RoPE on q (scaled into the log2 domain) and on the new key; Q^T fragments as bf16 hi + lo --------------------------------------------
+  const float qsc = rsqrtf((float)d) * 1.4426950408889634f;
+  float qv[4][8], kn[4][8];
+  {
+    float qa[4][8], ka[4][8], cs[2][8], sn[2][8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qa[s][0] = qr[s][0].x; qa[s][1] = qr[s][0].y; qa[s][2] = qr[s][0].z; qa[s][3] = qr[s][0].w; qa[s][4] = qr[s][1].x; qa[s][5] = qr[s][1].y; qa[s][6] = qr[s][1].z; qa[s][7] = qr[s][1].w;
+      ka[s][0] = kr[s][0].x; ka[s][1] = kr[s][0].y; ka[s][2] = kr[s][0].z; ka[s][3] = kr[s][0].w; ka[s][4] = kr[s][1].x; ka[s][5] = kr[s][1].y; ka[s][6] = kr[s][1].z; ka[s][7] = kr[s][1].w;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { cs[s][2 * i] = rr[s][i].x; sn[s][2 * i] = rr[s][i].y; cs[s][2 * i + 1] = rr[s][i].z; sn[s][2 * i + 1] = rr[s][i].w; }
+    const float live = n < G ? qsc : 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {        // x * cos + rotate_half(x) * sin: element e < 64 pairs with e + 64
+        qv[s][j] = (qa[s][j] * cs[s][j] - qa[s + 2][j] * sn[s][j]) * live;
+        qv[s + 2][j] = (qa[s + 2][j] * cs[s][j] + qa[s][j] * sn[s][j]) * live;
+        kn[s][j] = ka[s][j] * cs[s][j] - ka[s + 2][j] * sn[s][j];
+        kn[s + 2][j] = ka[s + 2][j] * cs[s][j] + ka[s][j] * sn[s][j];
+      }
+  }
+  att_raw qhi[4], qlo[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) gq_split(qv[s], qhi[s], qlo[s]);
+  // the new token is dealt with HERE so that the fp32 q / k registers are dead before the key loop (its cache slot is masked there: kidx < pos)
+  if (split == 0 && wave == NW - 1) {
+    // the new token's score per q head, from the projection registers (its cache slot is written below, by this workgroup only)
+    float dd = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dd = fmaf(qv[s][j], kn[s][j], dd);
+    dd += __shfl_xor(dd, 16);
+    dd += __shfl_xor(dd, 32);
+    if (g == 0 && n < G) s_new[n] = dd;
+  }
+  if (split == 0 && wave == 0 && n == 0) {          // one writer per (row, kv head): append the rotated key at slot pos
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      att_raw pk;
+      pk.x = gq_pk(kn[s][0], kn[s][1]); pk.y = gq_pk(kn[s][2], kn[s][3]); pk.z = gq_pk(kn[s][4], kn[s][5]); pk.w = gq_pk(kn[s][6], kn[s][7]);
+      *reinterpret_cast<att_raw*>(kc + (int64_t)pos * d + 32 * s + 8 * g) = pk;
+    }
+  }
+  // ---- key tiles ----------------------------------------------------------------------------------------------------------------------------
+  issue(1, ks + 32 * (wave + NW), kv.s_max - 1);      // second tile of this wave: requested once the fp32 q / k registers are free
+  gq_f32x4 oacc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) oacc[dt] = gq_f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_part = 0.f;
+  auto consume = [&](int buf, int key0) {
+    gq_f32x4 sc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      sc[t] = gq_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq_frag(kraw[buf][t][s]), gq_frag(qhi[s]), sc[t], 0, 0, 0);
+        sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq_frag(kraw[buf][t][s]), gq_frag(qlo[s]), sc[t], 0, 0, 0);
+      }
+    }
+    float p[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kidx = key0 + 16 * t + 4 * g + j;
+        p[4 * t + j] = kidx < ke ? sc[t][j] : -INFINITY;
+        tmax = fmaxf(tmax, p[4 * t + j]);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);            // finite: the caller only passes tiles with key0 < ke
+    const float corr = ex2(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[j] = ex2(p[j] - m_new); ps += p[j]; }
+    l_part = l_part * corr + ps;
+    m_run = m_new;
+    att_raw phi, plo;
+    gq_split(p, phi, plo);
+    // value fragments: keys past the position may hold anything (0 x NaN): scrub them
+    const int left0 = ke - (key0 + 4 * g), left1 = left0 - 16;
+    const unsigned a0 = left0 >= 2 ? 0xffffffffu : (left0 == 1 ? 0x0000ffffu : 0u), a1 = left0 >= 4 ? 0xffffffffu : (left0 == 3 ? 0x0000ffffu : 0u);
+    const unsigned b0 = left1 >= 2 ? 0xffffffffu : (left1 == 1 ? 0x0000ffffu : 0u), b1 = left1 >= 4 ? 0xffffffffu : (left1 == 3 ? 0x0000ffffu : 0u);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      att_raw a;
+      a.x = vraw[buf][dt][0].x & a0; a.y = vraw[buf][dt][0].y & a1; a.z = vraw[buf][dt][1].x & b0; a.w = vraw[buf][dt][1].y & b1;
+      gq_f32x4 o = oacc[dt];
+      o[0] *= corr; o[1] *= corr; o[2] *= corr; o[3] *= corr;
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq_frag(a), gq_frag(phi), o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq_frag(a), gq_frag(plo), o, 0, 0, 0);
+      oacc[dt] = o;
+    }
+  };
+  for (int key0 = ks + 32 * wave; key0 < ke; key0 += 64 * NW) {       // two tiles in flight per wave, buffers with fixed roles
+    consume(0, key0);
+    if (key0 + 64 * NW < ke) issue(0, key0 + 64 * NW, kv.s_max - 1);
+    if (key0 + 32 * NW >= ke) break;
+    consume(1, key0 + 32 * NW);
+    if (key0 + 96 * NW < ke) issue(1, key0 + 96 * NW, kv.s_max - 1);
+  }
+  // ---- this wave's (m, l, O) to LDS ------------------------------------------------------------------------------------------------------------
+  float l_tot = l_part + __shfl_xor(l_part, 16);
+  l_tot += __shfl_xor(l_tot, 32);
+  if (n < G) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+      *reinterpret_cast<float4*>(&so[wave][n][dt * 16 + 4 * g]) = make_float4(oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+    if (g == 0) { so[wave][n][128] = m_run; so[wave][n][129] = l_tot; }
+  }
+  __syncthreads();
+  // ---- merge: thread (q head, d) folds the waves' partials and the new token -----------------------------------------------------------------
+  const float* vnew = row + (int64_t)(heads + kv.kv_heads + kvh) * d;
+  float* pp = nullptr;
+  for (int o = tid; o < G * d; o += NW * 64) {
+    const int qh = o >> 7, dd = o & 127;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, so[w][qh][128]);
+    float sn = -INFINITY, vn = 0.f;
+    if (split == 0) { sn = s_new[qh]; vn = vnew[dd]; M = fmaxf(M, sn); }
+    float num = 0.f, den = 0.f;
+    if (M > -INFINITY) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float wgt = ex2(so[w][qh][128] - M);          // a wave without keys has m = -inf: weight 0
+        den = fmaf(wgt, so[w][qh][129], den);
+        num = fmaf(wgt, so[w][qh][dd], num);
+      }
+      if (split == 0) { const float wgt = ex2(sn - M); den += wgt; num = fmaf(wgt, vn, num); }
+    }
+    if (nsplit == 1) {
+      out[(int64_t)r * ldo + (int64_t)(kvh * G + qh) * d + dd] = num / den;
+    } else {
+      pp = part + (((int64_t)r * heads + kvh * G + qh) * nsplit + split) * (d + 2);
+      pp[2 + dd] = num;
+      if (dd == 0) { pp[0] = M; pp[1] = den; }
+    }
+    if (split == 0 && qh == 0) {                       // append v (key-major and transposed copies) at slot pos
+      const bf16_t vb = (bf16_t)bf16_bits(vn);
+      vc[(int64_t)pos * d + dd] = vb;
+      vt[(int64_t)dd * kv.s_max + pos] = vb;
+    }
+  }
+  if (nsplit == 1) return;
+  // split keys: the workgroup that draws the last ticket of its (row, kv head) folds the partials of all G heads
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int tk = __hip_atomic_fetch_add(&tickets[r * heads + kvh * G], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (tk == nsplit - 1);
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&tickets[r * heads + kvh * G], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  for (int o = tid; o < G * d; o += NW * 64) {
+    const int qh = o >> 7, dd = o & 127;
+    const float* p0 = part + (((int64_t)r * heads + kvh * G + qh) * nsplit) * (d + 2);
+    float MM = -INFINITY;
+    for (int sg = 0; sg < nsplit; ++sg) MM = fmaxf(MM, p0[sg * (d + 2)]);
+    float nn = 0.f, dn = 0.f;
+    for (int sg = 0; sg < nsplit; ++sg) {
+      const float* ps = p0 + sg * (d + 2);
+      if (ps[0] == -INFINITY) continue;                 // a split without keys
+      const float w = ex2(ps[0] - MM);
+      dn = fmaf(w, ps[1], dn);
+      nn = fmaf(w, ps[2 + dd], nn);
+    }
+    out[(int64_t)r * ldo + (int64_t)(kvh * G + qh) * d + dd] = nn / dn;
+  }
+}
+
+int g_gqa = 1;     // tuning hook "attn_gqa": 0 = the per-head kernel
+
 }  // namespace
 
 // 1 launched, 0 not covered (caller falls back to the generic kernel), < 0 error.  part / tickets: split-key workspace or null (nsplit = 1)
@@ -262,11 +539,20 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
   if (((uintptr_t)qkv % 16) || (ld_qkv % 4) || ((uintptr_t)rope % 16) || ((uintptr_t)kv->k % 16) || ((uintptr_t)kv->v % 16)) return 0;
   if (!part || !tickets || nsplit < 1) nsplit = 1;
   if (nsplit > 16) nsplit = 16;
+  const int G = heads / kv->kv_heads;
+  if (g_gqa && kv->vt && G <= GQ_MAXG && kv->s_max % 32 == 0 && kv->s_max >= 64 && ((uintptr_t)kv->vt % 8) == 0) {
+    hipLaunchKernelGGL((attn_decode_gqa_kernel<8>), dim3(kv->kv_heads, R, nsplit), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_attn_decode (gqa): %s", hipGetErrorString(e));
+    return 1;
+  }
   hipLaunchKernelGGL((attn_decode_kernel<8>), dim3(heads, R, nsplit), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_attn_decode: %s", hipGetErrorString(e));
   return 1;
 }
+
+void vv_attn_decode_set_gqa(int on) { g_gqa = on; }
 
 #ifdef VV_CF_TIMING
 extern "C" int vv_attn_debug_times(unsigned long long* out8, int reset) {
