@@ -101,10 +101,11 @@ typedef struct vv_kv {
   void* k;
   void* v;
   int kvdt, layers, rows, kv_heads, s_max, head_dim;
-  void* vt;   /* optional transposed value cache [layers][rows][kv_heads][head_dim][s_max] (same dtype): vv_rope_store keeps it in step with v
-                 for the rows it stores, and prompt-sized vv_attn calls (bf16, head_dim 128, s_max % 32 == 0) then run both attention products on
-                 the matrix cores without a transpose; NULL: the VALU kernels.  vv_attn_decode appends to it as it appends to v, so a prompt-sized call
-                 at any position after any number of decode steps sees every cached value.  Need not be zero-initialised. */
+  void* vt;   /* optional transposed value cache in 32-key tiles, [layers][rows][kv_heads][s_max / 32][head_dim][32] (same dtype, same size as v):
+                 element (d, s) of a head lives at (s / 32) * 32 * head_dim + d * 32 + s % 32, so one tile is 8 KB of contiguous memory whose rows are
+                 the A-operand fragments of the matrix-core P.V product.  vv_rope_store and vv_attn_decode keep it in step with v; with it (bf16,
+                 head_dim 128, s_max % 32 == 0) prompt-sized vv_attn calls and split-key decode steps run both attention products on the matrix
+                 cores without a transpose; NULL: the VALU kernels.  Need not be zero-initialised. */
 } vv_kv;
 
 /* rope_table[R][head_dim/2][2] = {cos, sin}(lens[r] * inv_freq[i]): computed once per step, shared by all layers */

@@ -44,6 +44,12 @@ _PARITY = []
 _CURRENT = {"id": None}
 
 
+def pytest_deselected(items):
+    if items:
+        cfg = items[0].config
+        cfg._vv_deselected = getattr(cfg, "_vv_deselected", 0) + len(items)
+
+
 @pytest.hookimpl(tryfirst=True)
 def pytest_runtest_setup(item):
     _CURRENT["id"] = item.nodeid
@@ -53,7 +59,9 @@ def pytest_sessionfinish(session, exitstatus):
     if not _PARITY:
         return
     import json
-    out = os.environ.get("VV_PARITY_OUT") or os.path.join(ROOT, "gpurun_out", "r03_parity_errors.json")
+    # a partial run (-k / one file) must not overwrite the record of a whole-suite run
+    whole = getattr(session, "testscollected", 0) - getattr(session.config, "_vv_deselected", 0) >= 200
+    out = os.environ.get("VV_PARITY_OUT") or os.path.join(ROOT, "gpurun_out", "r03_parity_errors.json" if whole else "r03_parity_errors.partial.json")
     try:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         by_test = {}
@@ -77,3 +85,9 @@ def rel_rms(a, b, what=None):
         rec["what"] = str(what)
     _PARITY.append(rec)
     return e
+
+
+def vt_tiles(v):
+    """vv_kv.vt layout of a key-major value cache v[..., s_max, d]: 32-key tiles [..., s_max / 32, d, 32] (include/vv_hip.h)."""
+    *lead, s_max, d = v.shape
+    return v.reshape(*lead, s_max // 32, 32, d).transpose(-1, -2).contiguous()

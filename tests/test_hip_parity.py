@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_rms
+from conftest import load_golden, rel_rms, vt_tiles
 
 pytestmark = pytest.mark.gpu
 
@@ -823,7 +823,7 @@ def test_prompt_attention_matrix_core_vs_torch(lib, heads, kv_heads, R, pos0):
     qkv = torch.randn(R, ld, generator=g)
     lens = torch.arange(pos0, pos0 + R, dtype=torch.int32)
     crow = torch.ones(R, dtype=torch.int32)
-    kd, vd, vtd, qd, ld_, cd = kc.cuda(), vc.cuda(), vc.transpose(-1, -2).contiguous().cuda(), qkv.cuda(), lens.cuda(), crow.cuda()
+    kd, vd, vtd, qd, ld_, cd = kc.cuda(), vc.cuda(), vt_tiles(vc).cuda(), qkv.cuda(), lens.cuda(), crow.cuda()
     out = torch.full((R, heads * d), float("nan"), device="cuda")
     kv = L.KV(kd.data_ptr(), vd.data_ptr(), L.VV_BF16, layers, rows, kv_heads, s_max, d, vtd.data_ptr())
     L.check(l.vv_attn(qd.data_ptr(), ld, R, heads, C.byref(kv), layer, ld_.data_ptr(), cd.data_ptr(), out.data_ptr(), heads * d, None), "vv_attn")

@@ -10,7 +10,7 @@ SO = os.path.join(ROOT, "tools", "bin", "libvv_hip_cft.so")
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    src = [f for f in sorted(glob.glob(os.path.join(ROOT, "vibevoice_rocm_amd", "csrc", "*.hip"))) if not f.endswith("vv_chain.hip")]
+    src = sorted(glob.glob(os.path.join(ROOT, "vibevoice_rocm_amd", "csrc", "*.hip")))
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DVV_CF_TIMING", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "vibevoice_rocm_amd", "csrc")] + src + ["-o", SO]
     subprocess.check_call(cmd)
@@ -127,19 +127,22 @@ def run_gemv():
         print(f"gemv m={m} n={n} k={k} dual={int(dual)}: " + "  ".join(f"{nm} {v:5.0f}" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us (block 0)", flush=True)
 
 
-def run_attn():
+def run_attn(gqa=0):
     import torch
     sys.path.insert(0, ROOT)
     from vibevoice_rocm_amd import _lib as L
     lib = C.CDLL(SO)
     assert lib.vv_init() == 0
+    lib.vv_tune(b"attn_gqa", gqa)
     heads, kvh, d, layers, R = 12, 2, 128, 4, 2
-    for S in (450, 900):
+    for S in (64, 450, 900):
         s_max = 1024
         k = torch.randn(layers, R, kvh, s_max, d, device="cuda").bfloat16()
         v = torch.randn(layers, R, kvh, s_max, d, device="cuda").bfloat16()
+        vt = torch.randn(layers, R, kvh, s_max // 32, d, 32, device="cuda").bfloat16()
         kv = L.KV()
         kv.k, kv.v, kv.layers, kv.rows, kv.kv_heads, kv.s_max, kv.head_dim, kv.kvdt = k.data_ptr(), v.data_ptr(), layers, R, kvh, s_max, d, L.VV_BF16
+        kv.vt = vt.data_ptr()
         qkv = torch.randn(R, (heads + 2 * kvh) * d, device="cuda")
         lens = torch.tensor([S, S // 4], dtype=torch.int32, device="cuda")
         inv = (1.0 / (1e6 ** (torch.arange(0, d, 2).float() / d))).cuda()
@@ -164,8 +167,8 @@ def run_attn():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["attn"]:
-        run_attn()
+    if sys.argv[1:2] == ["attn"]:
+        run_attn(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
         sys.exit(0)
     if sys.argv[1:] == ["gemv"]:
         run_gemv()

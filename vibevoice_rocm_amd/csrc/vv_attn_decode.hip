@@ -189,9 +189,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
       *reinterpret_cast<att_raw*>(kc + (int64_t)pos * d + e0) = pk;
       *reinterpret_cast<att_raw*>(vc + (int64_t)pos * d + e0) = pv;
       if (kv.vt) {                               // the transposed copy the matrix-core prompt attention reads stays in step with v
-        bf16_t* vtc = reinterpret_cast<bf16_t*>(kv.vt) + base + pos;
+        bf16_t* vtc = reinterpret_cast<bf16_t*>(kv.vt) + base + (int64_t)(pos >> 5) * (32 * d) + (pos & 31);     // 32-key tiles [tile][d][32]
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) vtc[(int64_t)(e0 + j) * kv.s_max] = (bf16_t)bf16_bits(vn[j]);
+        for (int j = 0; j < EPL; ++j) vtc[(e0 + j) * 32] = (bf16_t)bf16_bits(vn[j]);
       }
     }
   }
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
 //                                                  queries n >= G are zero columns
 //   softmax  the accumulator has the query on the lane: lane (n, g) holds keys 4 g + {0..3} of each 16-key tile; running maximum per query
 //            (two cross-row exchanges per 32 keys), sum kept per lane and folded once at the end; log2 domain
-//   output   O^T[d, q] += V^T[d, key] . P[key, q]  A = V^T from the transposed value cache vv_kv.vt (two 8-B loads per 16 d x 32 keys), B = P
-//                                                  straight from the score registers (key slot 8 g + j of the 32-deep step = the lane's own
-//                                                  eight scores), again as bf16 hi + lo
+//   output   O^T[d, q] += V^T[d, key] . P[key, q]  A = V^T from the tile-major transposed value cache vv_kv.vt (one 16-B load per 16 d x 32 keys,
+//                                                  a whole key tile is 8 KB of contiguous memory), B = P straight from the score registers
+//                                                  (key slot 8 g + j of the 32-deep step = the lane's own eight scores), again as bf16 hi + lo
 // Each of the NW waves walks 32-key tiles wave, wave + NW, ...; the waves' (m, l, O) meet in LDS once.  The new token's score and value come
 // from the projection registers; the workgroup of split 0 appends k (rotated), v and the transposed v at slot pos.
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -296,6 +296,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   __shared__ __attribute__((aligned(16))) float so[NW][GQ_MAXG][GQ_PITCH];     // per wave and query: O[128], then m, l
   __shared__ float s_new[GQ_MAXG];
   __shared__ int s_last;
+#ifdef VV_CF_TIMING
+  long long tprev_ = wall_clock64();
+#endif
   const int kvh = blockIdx.x, r = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   const int64_t base = ((((int64_t)layer * kv.rows + r) * kv.kv_heads + kvh) * kv.s_max) * d;
   bf16_t* kc = reinterpret_cast<bf16_t*>(kv.k) + base;
   bf16_t* vc = reinterpret_cast<bf16_t*>(kv.v) + base;
-  bf16_t* vt = reinterpret_cast<bf16_t*>(kv.vt) + base;   // [d][s_max]
+  bf16_t* vt = reinterpret_cast<bf16_t*>(kv.vt) + base;   // [s_max / 32][d][32]
   // ---- requests: q chunks of this lane's head, the new k chunks, RoPE table, and (unsplit contexts) the first two key tiles -------------
   const float* qp = row + (int64_t)(kvh * G + nq) * d + 8 * g;
   const float* kp = row + (int64_t)(heads + kvh) * d + 8 * g;
@@ -320,22 +323,21 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i) rr[s][i] = *reinterpret_cast<const float4*>(rp + 32 * s + 2 * i);     // {cos, sin} x 2 per float4
-  att_raw kraw[2][2][4];            // [buffer][16-key tile][k-step]
-  gq_u32x2 vraw[2][8][2];           // [buffer][d tile][16-key tile]
+  att_raw kraw[2][2][4];            // [buffer][16-row score tile][k-step]
+  att_raw vraw[2][8];               // [buffer][d tile]: keys 8 g .. 8 g + 7 of the 32-key tile for d row 16 dt + n
+  // Row i of score tile t holds key 8 (i >> 2) + 4 t + (i & 3) of the 32-key tile: lane (n, g)'s eight scores are then keys 8 g .. 8 g + 7 in
+  // order - the k slots 8 g + j of the P.V step - and its V^T fragment is ONE 16-byte load from the tile-major transposed cache.
+  const int krow = 8 * (n >> 2) + (n & 3);
   auto issue = [&](int buf, int key0, int kmax_valid) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int key = min(key0 + 16 * t + n, kmax_valid);
+      const int key = min(key0 + krow + 4 * t, kmax_valid);
 #pragma unroll
       for (int s = 0; s < 4; ++s) kraw[buf][t][s] = *reinterpret_cast<const att_raw*>(kc + (int64_t)key * d + 32 * s + 8 * g);
     }
-    const int kb = min(key0, kv.s_max - 32) + 4 * g;                  // 8-B fragments never leave the row: s_max % 32 == 0
+    const bf16_t* vp = vt + (int64_t)(min(key0, kv.s_max - 32) >> 5) * (32 * d) + n * 32 + 8 * g;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const bf16_t* vp = vt + (int64_t)(dt * 16 + n) * kv.s_max + kb;
-      vraw[buf][dt][0] = *reinterpret_cast<const gq_u32x2*>(vp);
-      vraw[buf][dt][1] = *reinterpret_cast<const gq_u32x2*>(vp + 16);
-    }
+    for (int dt = 0; dt < 8; ++dt) vraw[buf][dt] = *reinterpret_cast<const att_raw*>(vp + dt * 16 * 32);
   };
   const bool spec = nsplit == 1;     // unsplit: the first tiles are requested before the position is known (masked / scrubbed when consumed)
   if (spec) issue(0, 32 * wave, kv.s_max - 1);
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   const int per = ((pos + nsplit - 1) / nsplit + 31) & ~31;          // keys per split, whole tiles
   const int ks = split * per, ke = min(pos, ks + per);
   if (!spec) issue(0, ks + 32 * wave, kv.s_max - 1);
+  ASTAMP(0);                                       // requests out, position known
   // ---- RoPE on q (scaled into the log2 domain) and on the new key; Q^T fragments as bf16 hi + lo --------------------------------------------
   const float qsc = rsqrtf((float)d) * 1.4426950408889634f;
   float qv[4][8], kn[4][8];
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
       *reinterpret_cast<att_raw*>(kc + (int64_t)pos * d + 32 * s + 8 * g) = pk;
     }
   }
+  ASTAMP(1);                                       // q / k / rope landed, RoPE, split, new token
   // ---- key tiles ----------------------------------------------------------------------------------------------------------------------------
   issue(1, ks + 32 * (wave + NW), kv.s_max - 1);      // second tile of this wave: requested once the fp32 q / k registers are free
   gq_f32x4 oacc[8];
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int kidx = key0 + 16 * t + 4 * g + j;
+        const int kidx = key0 + 8 * g + 4 * t + j;
         p[4 * t + j] = kidx < ke ? sc[t][j] : -INFINITY;
         tmax = fmaxf(tmax, p[4 * t + j]);
       }
@@ -430,13 +434,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     att_raw phi, plo;
     gq_split(p, phi, plo);
     // value fragments: keys past the position may hold anything (0 x NaN): scrub them
-    const int left0 = ke - (key0 + 4 * g), left1 = left0 - 16;
-    const unsigned a0 = left0 >= 2 ? 0xffffffffu : (left0 == 1 ? 0x0000ffffu : 0u), a1 = left0 >= 4 ? 0xffffffffu : (left0 == 3 ? 0x0000ffffu : 0u);
-    const unsigned b0 = left1 >= 2 ? 0xffffffffu : (left1 == 1 ? 0x0000ffffu : 0u), b1 = left1 >= 4 ? 0xffffffffu : (left1 == 3 ? 0x0000ffffu : 0u);
+    const int left = ke - (key0 + 8 * g);
+    auto keep = [&](int lo) { return left >= lo + 2 ? 0xffffffffu : (left == lo + 1 ? 0x0000ffffu : 0u); };
+    const unsigned a0 = keep(0), a1 = keep(2), a2 = keep(4), a3 = keep(6);
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
       att_raw a;
-      a.x = vraw[buf][dt][0].x & a0; a.y = vraw[buf][dt][0].y & a1; a.z = vraw[buf][dt][1].x & b0; a.w = vraw[buf][dt][1].y & b1;
+      a.x = vraw[buf][dt].x & a0; a.y = vraw[buf][dt].y & a1; a.z = vraw[buf][dt].z & a2; a.w = vraw[buf][dt].w & a3;
       gq_f32x4 o = oacc[dt];
       o[0] *= corr; o[1] *= corr; o[2] *= corr; o[3] *= corr;
       o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gq_frag(a), gq_frag(phi), o, 0, 0, 0);
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     consume(1, key0 + 32 * NW);
     if (key0 + 96 * NW < ke) issue(1, key0 + 96 * NW, kv.s_max - 1);
   }
+  ASTAMP(2);                                       // key tiles
   // ---- this wave's (m, l, O) to LDS ------------------------------------------------------------------------------------------------------------
   float l_tot = l_part + __shfl_xor(l_part, 16);
   l_tot += __shfl_xor(l_tot, 32);
@@ -461,6 +466,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     if (g == 0) { so[wave][n][128] = m_run; so[wave][n][129] = l_tot; }
   }
   __syncthreads();
+  ASTAMP(3);                                       // partials in LDS, barrier (waits for the slowest wave)
   // ---- merge: thread (q head, d) folds the waves' partials and the new token -----------------------------------------------------------------
   const float* vnew = row + (int64_t)(heads + kv.kv_heads + kvh) * d;
   float* pp = nullptr;
@@ -491,9 +497,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     if (split == 0 && qh == 0) {                       // append v (key-major and transposed copies) at slot pos
       const bf16_t vb = (bf16_t)bf16_bits(vn);
       vc[(int64_t)pos * d + dd] = vb;
-      vt[(int64_t)dd * kv.s_max + pos] = vb;
+      vt[(int64_t)(pos >> 5) * (32 * d) + dd * 32 + (pos & 31)] = vb;
     }
   }
+  ASTAMP(4);                                       // merge + store
   if (nsplit == 1) return;
   // split keys: the workgroup that draws the last ticket of its (row, kv head) folds the partials of all G heads
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   }
 }
 
-int g_gqa = 1;     // tuning hook "attn_gqa": 0 = the per-head kernel
+int g_gqa = 1;     // tuning hook "attn_gqa"
 
 }  // namespace
 
@@ -540,7 +547,13 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
   if (!part || !tickets || nsplit < 1) nsplit = 1;
   if (nsplit > 16) nsplit = 16;
   const int G = heads / kv->kv_heads;
-  if (g_gqa && kv->vt && G <= GQ_MAXG && kv->s_max % 32 == 0 && kv->s_max >= 64 && ((uintptr_t)kv->vt % 8) == 0) {
+  // The grouped kernel pays in the long-form regime (the reference's 45 - 90 minute dialogues: 32K - 64K contexts), where K / V bytes set the
+  // time: one K / V pass per KV head instead of one per q head.  Measured LLM step, per-head -> grouped (tools/mb_attn_long.py, MI355X):
+  // 7B S = 7 200: 4.46 -> 3.88 ms, S = 32 000: 6.39 -> 4.43 ms; 1.5B S = 16 000: 2.16 -> 2.07 ms, S = 32 000: 2.79 -> 2.41 ms.  Below
+  // ~24K cached key rows per (layer, cache row) its few workgroups pull a (row, KV head)'s whole cache through one CU's address path
+  // (16 -> 12 us per layer at S = 370 against 7.4 us for the per-head kernel's 24 workgroups; phase timing: tools/convffn_phase.py attn 2),
+  // so short contexts keep the per-head kernel.  g_gqa (tuning hook "attn_gqa"): 1 = by that rule, 2 = always, 0 = never.
+  if (g_gqa && ((nsplit > 1 && (long)kv->kv_heads * kv->s_max >= 24576) || g_gqa == 2) && kv->vt && G <= GQ_MAXG && kv->s_max % 32 == 0 && kv->s_max >= 64 && ((uintptr_t)kv->vt % 8) == 0) {
     hipLaunchKernelGGL((attn_decode_gqa_kernel<8>), dim3(kv->kv_heads, R, nsplit), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_attn_decode (gqa): %s", hipGetErrorString(e));

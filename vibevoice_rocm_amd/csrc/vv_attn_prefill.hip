@@ -10,8 +10,9 @@
 //   O^T[d, q]   += V^T[d, key] . P[key, q]  B = P straight from the S^T accumulator registers (cdna_hip_programming.md, "An accumulator
 //                                           tile as the next MFMA's operand": element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)),
 //                                           A = V^T rows in that key order: two 8-byte loads per fragment from the TRANSPOSED value
-//                                           cache vv_kv.vt [layers][rows][kv_heads][head_dim][s_max] that vv_rope_store maintains for
-//                                           prompt rows (the decode kernel keeps reading the key-major copy)
+//                                           cache vv_kv.vt, kept in 32-key tiles [..][s_max / 32][head_dim][32] (a key tile is 8 KB of
+//                                           contiguous memory: one load instruction of the wave covers a 2 KB run instead of 32 rows
+//                                           s_max elements apart) by vv_rope_store and vv_attn_decode
 // The 6 / 7 q heads of a GQA group read the same K / V tiles (L2 hits); the K fragments of tile t + 1 are requested before tile t is
 // scored.  Heaviest query tiles (most key tiles under the causal mask) are dispatched first.
 #include <hip/hip_runtime.h>
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
   const int n_tiles = (kmax + 31) >> 5;
   const int64_t base = ((((int64_t)layer * kv.rows + crow) * kv.kv_heads + kvh) * kv.s_max) * d;
   const bf16_t* kc = reinterpret_cast<const bf16_t*>(kv.k) + base;          // [s_max][d]
-  const bf16_t* vt = reinterpret_cast<const bf16_t*>(kv.vt) + base;         // [d][s_max]
+  const bf16_t* vt = reinterpret_cast<const bf16_t*>(kv.vt) + base;         // [s_max / 32][d][32]
   f32x16 oacc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(const float* qkv, int6
     u32x2 vf[4][2][2];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      const bf16_t* vp = vt + (int64_t)(dt * 32 + r) * kv.s_max + key0 + 4 * h;
+      const bf16_t* vp = vt + (int64_t)t * (32 * d) + (dt * 32 + r) * 32 + 4 * h;       // 32-key tiles: [tile][d][32]
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         vf[dt][s][0] = *reinterpret_cast<const u32x2*>(vp + 16 * s);

@@ -29,7 +29,7 @@ int vv_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* vv_last_error(void) { return g_err; }
-extern "C" int vv_abi_version(void) { return 4; }   // 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL); 4: vv_block.dw_last / hs, vv_block_mid
+extern "C" int vv_abi_version(void) { return 5; }   // 5: vv_kv.vt in 32-key tiles, vv_attn_decode maintains it, vv_advance_lens tok_start < 0; 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL); 4: vv_block.dw_last / hs, vv_block_mid
 int vv_mixer_init();
 extern "C" int vv_init(void) {
   VV_TRY(vv_mixer_init());
@@ -688,11 +688,11 @@ __global__ __launch_bounds__(256) void rope_store_kernel(float* qkv, int64_t ld,
     }
   }
   const float* vrow = row + (heads + kv.kv_heads) * d;
-  KT* vtc = reinterpret_cast<KT*>(kv.vt);                   // optional transposed copy [.., d, s_max] for the matrix-core prompt attention
+  KT* vtc = reinterpret_cast<KT*>(kv.vt);                   // optional transposed copy in 32-key tiles [.., s_max / 32, d, 32] for the matrix-core attention kernels
   for (int idx = threadIdx.x; idx < kv.kv_heads * d; idx += blockDim.x) {
     const int h = idx / d, i = idx - h * d;
     kv_store<KT>(vc + base + ((int64_t)h * kv.s_max + pos) * d + i, vrow[idx]);
-    if (vtc) kv_store<KT>(vtc + base + ((int64_t)h * d + i) * kv.s_max + pos, vrow[idx]);
+    if (vtc) kv_store<KT>(vtc + base + (int64_t)h * kv.s_max * d + (int64_t)(pos >> 5) * 32 * d + i * 32 + (pos & 31), vrow[idx]);
   }
 }
 

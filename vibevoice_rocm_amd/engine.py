@@ -184,9 +184,9 @@ class Engine:
                 kv = L.KV()
                 kv.k, kv.v = self._kv_t[0].data_ptr(), self._kv_t[1].data_ptr()
                 if self.kv_dtype == torch.bfloat16 and cfg.head_dim == 128:
-                    # transposed value cache [.., head_dim, s_max] for the matrix-core prompt attention (written by vv_rope_store, i.e. for
-                    # prompt rows only; the decode step appends to the key-major copy alone)
-                    self._kv_vt = torch.zeros((cfg.layers, 2, cfg.kv_heads, cfg.head_dim, s_max), dtype=self.kv_dtype, device=self.device)
+                    # transposed value cache in 32-key tiles [.., s_max / 32, head_dim, 32] for the matrix-core attention kernels (kept in step
+                    # with v by vv_rope_store for prompt rows and by vv_attn_decode for decode steps)
+                    self._kv_vt = torch.empty((cfg.layers, 2, cfg.kv_heads, s_max // 32, cfg.head_dim, 32), dtype=self.kv_dtype, device=self.device)
                     kv.vt = self._kv_vt.data_ptr()
                 kv.kvdt = L.VV_F32 if self.kv_dtype == torch.float32 else L.VV_BF16
                 kv.layers, kv.rows, kv.kv_heads, kv.s_max, kv.head_dim = cfg.layers, 2, cfg.kv_heads, s_max, cfg.head_dim
