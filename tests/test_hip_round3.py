@@ -534,3 +534,4 @@ def test_decode_attention_gqa_vs_torch(heads, kv_heads, lens, s_max):
     for r in range(R):       # both kernels append the same bits
         assert torch.equal(k1[layer, r, :, lens[r]], k2[layer, r, :, lens[r]]) and torch.equal(v1[layer, r, :, lens[r]], v2[layer, r, :, lens[r]])
         assert torch.equal(vt1[layer, r, :, lens[r] // 32, :, lens[r] % 32], vt2[layer, r, :, lens[r] // 32, :, lens[r] % 32])
+

@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void block1d_kernel(const float* __restrict__ 
   }
 }
 
+
 int g_blocks = 256;           // persistent workgroups at C = 128 (1 per CU: 5.15 ms voice encode vs 5.18 at 512, 5.59 unbounded); tuning hook "block1d_blocks"
 
 template <int C>

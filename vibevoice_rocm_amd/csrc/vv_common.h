@@ -61,12 +61,14 @@ int vv_rmsnorm_rows(const float* x, int64_t ldx, const float* w, float eps, int 
 
 #ifdef __HIPCC__
 // GELU (exact-erf form) with erf from Abramowitz & Stegun 7.1.26: |erf error| <= 1.5e-7, one v_exp + one v_rcp + 6 FMA instead
-// of libm's erff (~4x the instructions).  Used only where the result is rounded to bf16 (2^-9 relative) right away - the hidden
+// of libm's erff (~4x the instructions).  The reciprocal is the hardware's v_rcp_f32 (1 ulp): __frcp_rn expands to the IEEE division
+// sequence (v_div_scale / v_div_fmas / v_div_fixup + Newton steps, ~10 more instructions per GELU), and these kernels are bound by
+// per-CU vector throughput (32 - 64 GELUs per lane per tile: tools/experiments/block1d_x3.hip.inc has the phase timings).  Used only where the result is rounded to bf16 (2^-9 relative) right away - the hidden
 // activation between the two FFN GEMMs of a conv block, where every lane evaluates dozens of them and erff was the longest
 // phase of the kernel.  fp32 outputs keep erff.
 __device__ __forceinline__ float vv_gelu_as(float v) {
   const float x = v * 0.70710678118654752440f, ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float erf_abs = 1.0f - poly * __expf(-ax * ax);
   return 0.5f * v * (1.0f + copysignf(erf_abs, x));

@@ -352,7 +352,7 @@ static size_t convnet_pad_floats(const vv_convnet* net, int64_t t_in, size_t* of
 // scratch histories of the one-row stage's blocks (<= 16 blocks x 6 rows x 2048 channels), see run_blocks
 #define VV_ROW_BLOCKS 16
 #define VV_ROW_HIST_FLOATS ((size_t)VV_ROW_BLOCKS * 6 * 2048)
-#define VV_CTX_ITEMS (VV_MAX_STAGES + 1 + 2 * VV_ROW_BLOCKS)   // capacity of a net's streaming-state move list
+#define VV_CTX_ITEMS (VV_MAX_STAGES + 1 + 16)   // capacity of a net's streaming-state move list (= vv_conv_ctx_batch's limit, vv_fused.hip)
 
 extern "C" size_t vv_convnet_ws_bytes(const vv_convnet* net, int64_t t_in, int decoder) {
   if (!net || t_in <= 0) return 0;
