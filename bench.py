@@ -179,6 +179,24 @@ def pmc_traffic(shape_key):
         return None, repr(e)
 
 
+def in_graph_durations():
+    """Per-shape in-graph kernel durations from profiles/r03_per_shape.csv (rocprofv3 --kernel-trace over hipGraph replays of real generate()
+    frames, tools/frame_trace.py) - only when profiles/r03_per_shape.sha names THIS kernel source, else ({}, reason)."""
+    import csv
+    base = os.path.join(ROOT, "profiles", "r03_per_shape")
+    try:
+        sha = open(base + ".sha").read().strip()
+        if sha != kernel_source_sha():
+            return {}, f"profiles/r03_per_shape.csv was measured on kernel source {sha}, this tree is {kernel_source_sha()}"
+        out = {}
+        for r in csv.DictReader(open(base + ".csv")):
+            if int(r["m"] or 0) > 0:
+                out[(int(r["m"]), int(r["n"]), int(r["k"]))] = float(r["avg_us"])
+        return out, "profiles/r03_per_shape.csv (rocprofv3 --kernel-trace, in-graph replays of real frames)"
+    except Exception as e:      # noqa: BLE001
+        return {}, repr(e)
+
+
 def llm_prefill_flops(cfg, L0):
     """2 x M x N x K over the Qwen2 linears of an L0-row prefill + causal attention (QK^T and PV, half the square)."""
     H, I, qd, kvd = cfg.hidden, cfg.inter, cfg.q_dim, cfg.kv_dim
@@ -674,15 +692,20 @@ def main():
         D, F = cfg.head_hidden, cfg.head_ffn
         head_shapes = {(2, F, D), (2, D, F), (2, cfg.latent, D)}          # re-read by every solver step: served from the Infinity Cache
 
+        ig, ig_note = in_graph_durations()
+
         def entry(e):
             cached = (e["m"], e["n"], e["k"]) in head_shapes
             traffic, tnote = pmc_traffic(f"{e['m']}x{e['n']}x{e['k']}")
-            return {"bound": "hbm", "kernel": f"gemv_stream_kernel (vv_linear m={e['m']} n={e['n']} k={e['k']} dual={e['dual']})",
+            us = ig.get((e["m"], e["n"], e["k"]))
+            in_graph = ({"avg_us": us, "achieved": round(e["weight_bytes"] / us / 1e3, 1), "frac": round(e["weight_bytes"] / us / 1e3 / HBM_PEAK_GBS, 4), "source": ig_note}
+                        if us else {"avg_us": None, "frac": None, "source": ig_note})
+            return {"bound": "hbm", "in_graph": in_graph, "kernel": f"gemv_stream_kernel (vv_linear m={e['m']} n={e['n']} k={e['k']} dual={e['dual']})",
                     "achieved": round(e["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_note": tnote, "avg_us": round(e["avg_us"], 2), "bytes_per_launch": e["weight_bytes"], "launches": e["count"],
                     "served_from": "infinity cache (weights re-read by every solver step; HBM sees them once per frame)" if cached else "hbm",
                     "timing": "HIP events on the launch stream around every eager launch of the timed frames (includes ~2-3 us of eager launch overhead "
-                              "a graph replay does not pay; profiles/r02_per_shape.csv has the in-graph durations)"}
+                              "a graph replay does not pay; `in_graph` carries the rocprofv3 duration of the same launch inside a hipGraph replay)"}
         result["roofline"] = entry(ents[0])
         hbm_ents = [e for e in ents if (e["m"], e["n"], e["k"]) not in head_shapes]
         if hbm_ents:

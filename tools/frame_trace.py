@@ -138,6 +138,10 @@ def reduce(path, out_prefix=None, model="1.5b"):
             open(out_prefix + "_frame_timeline.txt", "w").write(text)
         with open(out_prefix + ("_pmc_per_shape.csv" if is_pmc else "_per_shape.csv"), "w", newline="") as f:
             csv.writer(f).writerows(csv_rows)
+        if not is_pmc:       # ties the table to the kernel source it was measured on (bench.py reads the in-graph durations only when it matches)
+            sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+            import bench as _b
+            open(out_prefix + "_per_shape.sha", "w").write(_b.kernel_source_sha() + "\n")
         if is_pmc:      # profiles/pmc_traffic.json: HBM-side bytes per launch of the GEMV shapes, tied to the kernel source they were measured on
             import json
             sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])

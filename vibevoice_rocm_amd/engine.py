@@ -75,6 +75,7 @@ class Engine:
         self.token_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.logits_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.forced_host = torch.full((1,), -1, dtype=torch.int32).pin_memory()
+        self._forced_dev_val = -1                         # what forced_dev holds (see _set_forced)
         self.noise_host = torch.zeros(2, cfg.latent, dtype=torch.float32).pin_memory()   # double-buffered: the host runs a frame ahead
         self._noise_k = 0
         self._tok_event = torch.cuda.Event()
@@ -327,6 +328,17 @@ class Engine:
     # ---------------------------------------------------------------------------------------------------------
     # the three per-token phases used by generate()
     # ---------------------------------------------------------------------------------------------------------
+    def _set_forced(self, forced: Optional[int]):
+        """Device-side forced token (-1: none).  Uploaded only when it changes: in the steady state of a dialogue (greedy decoding, or a forced
+        schedule of speech_diffusion frames) the value repeats and the 4-byte H2D blit (~5 us on the frame's critical path) is skipped.  The
+        pinned word is rewritten only after the previous step's token has been awaited, i.e. after any earlier copy from it has executed."""
+        v = -1 if forced is None else int(forced)
+        if v == self._forced_dev_val:
+            return
+        self.forced_host[0] = v
+        self.forced_dev.copy_(self.forced_host, non_blocking=True)
+        self._forced_dev_val = v
+
     def _host_logits(self) -> torch.Tensor:
         with torch.cuda.stream(self.stream):
             self.logits_host.copy_(self.logits, non_blocking=True)
@@ -341,14 +353,12 @@ class Engine:
                 self._run("A1", self._seq_A1)
             tok = int(sample_fn(self._host_logits(), self.valid_ids))
             with torch.cuda.stream(self.stream):
-                self.forced_host[0] = tok
-                self.forced_dev.copy_(self.forced_host, non_blocking=True)
+                self._set_forced(tok)
                 self._run("A2", self._seq_A2, int(tok_start), int(tok_diff))
             self.stream.synchronize()
             return tok
         with torch.cuda.stream(self.stream):
-            self.forced_host[0] = -1 if forced is None else int(forced)
-            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._set_forced(forced)
             self._run("A", self._seq_A, int(tok_start), int(tok_diff))
             self.token_host.copy_(self.token_dev, non_blocking=True)
         if on_enqueued is not None:
@@ -363,8 +373,7 @@ class Engine:
                 self._logits()
             forced = int(sample_fn(self._host_logits(), self.valid_ids))
         with torch.cuda.stream(self.stream):
-            self.forced_host[0] = -1 if forced is None else int(forced)
-            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._set_forced(forced)
             self._select_token()
             self.token_host.copy_(self.token_dev, non_blocking=True)
         self.stream.synchronize()
@@ -397,8 +406,7 @@ class Engine:
         wakes up and decides; if the token turns out to be something else the caller rolls the speech state back
         (`rollback_speech_state`) - phase B touches nothing else that survives (x2 is rewritten by the embed phase)."""
         with torch.cuda.stream(self.stream):
-            self.forced_host[0] = -1 if forced is None else int(forced)
-            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._set_forced(forced)
             self._run("A", self._seq_A, int(tok_start), int(tok_diff))
             self.token_host.copy_(self.token_dev, non_blocking=True)
             self._tok_event.record(self.stream)
@@ -421,8 +429,7 @@ class Engine:
         """Lock-step batches (one Engine per sample, one host loop): enqueue phase A - and, with `spec_noise` = (noise, sde_noise), the
         speculative phase B behind it - without waiting; `decode_end` returns the token."""
         with torch.cuda.stream(self.stream):
-            self.forced_host[0] = -1 if forced is None else int(forced)
-            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+            self._set_forced(forced)
             self._run("A", self._seq_A, int(tok_start), int(tok_diff))
             self.token_host.copy_(self.token_dev, non_blocking=True)
             self._tok_event.record(self.stream)
