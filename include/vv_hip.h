@@ -309,6 +309,11 @@ typedef struct vv_connector { int wdt, din, hidden; const void* fc1; const float
 /* SpeechConnector.forward (modeling_vibevoice.py:58-69): out[R,hidden] (+)= fc2(RMSNorm(fc1 x)); accumulate != 0 adds
  * into `out` (acoustic + semantic sum, modeling_vibevoice_inference.py:665-667).  ws: R*hidden floats. */
 int vv_connector_forward(const vv_connector* c, const float* x, int R, float* out, int accumulate, float* ws, vv_stream_t stream);
+/* Both connectors of one generated frame: out[r, :] = acoustic_connector(latent) + semantic_connector(semfeat) for r < rows_out
+ * (modeling_vibevoice_inference.py:665-670; the positive and the negative branch consume the same embedding, :575-579).  Two launches
+ * (fc1 of both, fc2 of both with the RMSNorms in the prologue) when the weights are bf16, else the two connectors in turn.  ws: 2 * hidden floats. */
+int vv_connector_pair(const vv_connector* ac, const vv_connector* sem, const float* latent, const float* semfeat, float* out, int64_t ldo,
+                      int rows_out, float* ws, vv_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * hipGraph capture of whatever the caller enqueues between begin/end on `stream`.

@@ -535,3 +535,42 @@ def test_decode_attention_gqa_vs_torch(heads, kv_heads, lens, s_max):
         assert torch.equal(k1[layer, r, :, lens[r]], k2[layer, r, :, lens[r]]) and torch.equal(v1[layer, r, :, lens[r]], v2[layer, r, :, lens[r]])
         assert torch.equal(vt1[layer, r, :, lens[r] // 32, :, lens[r] % 32], vt2[layer, r, :, lens[r] // 32, :, lens[r] % 32])
 
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# both connectors of a frame in two launches
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset,dtype", [("1.5b", torch.bfloat16), ("mid", torch.bfloat16), ("mid", torch.float32), ("7b", torch.bfloat16)])
+def test_connector_pair_vs_oracle_and_two_calls(preset, dtype):
+    """vv_connector_pair (acoustic_connector(latent) + semantic_connector(features) of one frame, SpeechConnector modeling_vibevoice.py:58-69,
+    summed as modeling_vibevoice_inference.py:665-670, stored to both decode rows) against the oracle's two connectors and against the two
+    vv_connector_forward calls it replaces; fp32 weights take the sequential path inside the same entry point."""
+    _need_gpu()
+    import dataclasses
+    from oracle import vv_oracle as O
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.engine import Engine
+    from vibevoice_rocm_amd.synth import synth_state_dict_torch
+    base = VVConfig.preset(preset)
+    cfg = base if preset == "mid" else dataclasses.replace(base, layers=1, vocab=2048, head_layers=1, ac_depths=[1] * 7, sem_depths=[1] * 7)
+    sd = synth_state_dict_torch(cfg, 5, device="cuda:0", dtype=dtype)
+    eng = Engine(cfg, sd, device="cuda:0", dtype=dtype, use_graphs=False)
+    g = torch.Generator().manual_seed(3)
+    lat, sem = torch.randn(cfg.ac_dim, generator=g), torch.randn(cfg.sem_dim, generator=g)
+    sd_o = {k: (v.to(torch.bfloat16).float() if (v.dim() >= 2 and dtype == torch.bfloat16) else v.float()).cpu() for k, v in sd.items() if "_connector." in k}
+    want = (O.connector(sd_o, "model.acoustic_connector.", lat[None]) + O.connector(sd_o, "model.semantic_connector.", sem[None]))[0].numpy()
+    with torch.cuda.stream(eng.stream):
+        eng.latent.copy_(lat.cuda()); eng.sem.copy_(sem.cuda())
+        eng.x2.fill_(float("nan"))
+        eng._ck(eng.lib.vv_connector_pair(C.byref(eng.w.ac_conn), C.byref(eng.w.sem_conn), eng.latent.data_ptr(), eng.sem.data_ptr(), eng.x2.data_ptr(), cfg.hidden, 2,
+                                          eng.conn_ws.data_ptr(), eng.sp), "vv_connector_pair")
+        pair = eng.x2.clone()
+        eng._ck(eng.lib.vv_connector_forward(C.byref(eng.w.ac_conn), eng.latent.data_ptr(), 1, eng.x2.data_ptr(), 0, eng.conn_ws.data_ptr(), eng.sp), "a")
+        eng._ck(eng.lib.vv_connector_forward(C.byref(eng.w.sem_conn), eng.sem.data_ptr(), 1, eng.x2.data_ptr(), 1, eng.conn_ws.data_ptr(), eng.sp), "s")
+        two = eng.x2[0].clone()
+    eng.stream.synchronize()
+    assert torch.equal(pair[0], pair[1]), "both decode rows receive the same embedding"
+    e = rel_rms(pair[0].cpu().numpy(), want, f"connector pair {preset} {dtype} vs oracle")
+    e2 = rel_rms(pair[0].cpu().numpy(), two.cpu().numpy(), f"connector pair {preset} {dtype} vs two calls")
+    assert e < 1e-5 and e2 < 1e-5, f"connector pair: vs oracle {e:.3e}, vs two calls {e2:.3e}"
+    eng.close()

@@ -132,6 +132,7 @@ PROTOTYPES = {
     "vv_encoder_forward": (C.c_int, [C.POINTER(ConvNet), vp, i64, vp, vp, vp]),
     "vv_convnet_reset": (C.c_int, [C.POINTER(ConvNet), vp]),
     "vv_connector_forward": (C.c_int, [C.POINTER(Connector), vp, C.c_int, vp, C.c_int, vp, vp]),
+    "vv_connector_pair": (C.c_int, [C.POINTER(Connector), C.POINTER(Connector), vp, vp, vp, i64, C.c_int, vp, vp]),
     "vv_graph_begin": (C.c_int, [vp]),
     "vv_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "vv_graph_launch": (C.c_int, [vp, vp]),

@@ -37,6 +37,8 @@ bool vv_head_boundary_supported(const vv_head* h);
 int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
                            const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s);
 int vv_fused_init();
+int vv_launch_connector_pair(const vv_connector* ac, const vv_connector* sem, const float* latent, const float* semfeat, float* out, int64_t ldo, int rows_out,
+                             float* ws, hipStream_t s);   // 1 launched, 0 not covered
 int vv_head_modulations_fused(const vv_head* h, const void* c_bf16, int rows, float* const* mod, float* modf, hipStream_t s);   // 1 launched, 0 not covered
 struct vv_conv_ctx_item { float* pad; float* state; int ctx, T, C; const float* dw_w; float* hs; int affine; float scale, bias; };   // dw_w / hs (scatter only): also hs[c] = sum_k<6 dw_w[c, k] * new state[k, c]; affine (gather only): pad = state * scale + bias (the net's input rides along)
 int vv_conv_ctx_batch(const vv_conv_ctx_item* items, int n, int scatter, hipStream_t s);   // scatter 0: pad[0:ctx] <- state; 1: state <- pad[T : T + ctx]

@@ -520,6 +520,134 @@ __global__ __launch_bounds__(256) void adaln_lds_kernel(const bf16_t* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// both SpeechConnectors of a frame in two launches (modeling_vibevoice.py:58-69, modeling_vibevoice_inference.py:665-667):
+//   x_next = (fc2_a RMSNorm(fc1_a latent + b1_a) + b2_a) + (fc2_s RMSNorm(fc1_s sem + b1_s) + b2_s), stored to `rows_out` rows
+// They ran as 4 dependent GEMV launches + a row copy (24 us for 9.8 MB); fc1 of both is one launch (one output per thread, K = 64 / 128),
+// fc2 of both is one M = 1 GEMV over the two [H, H] matrices with the two RMSNorms in its prologue and the sum + both output rows in its epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+struct ConnPairArgs {
+  const bf16_t* fc1_a; const float* b1_a; int din_a; const bf16_t* fc1_s; const float* b1_s; int din_s;
+  const float* xa; const float* xs;                     // latent [din_a], semantic features [din_s]
+  float* t;                                             // [2, H] fc1 outputs (workspace)
+  const float* nw_a; const float* nw_s; const bf16_t* fc2_a; const bf16_t* fc2_s; const float* b2_a; const float* b2_s;
+  float* out; int64_t ldo; int rows_out; int H; float eps;
+};
+
+__global__ __launch_bounds__(256) void conn_fc1_pair_kernel(const ConnPairArgs a) {
+  __shared__ __attribute__((aligned(16))) float xin[512];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.din_a + a.din_s; i += 256) xin[i] = i < a.din_a ? a.xa[i] : a.xs[i - a.din_a];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + tid;
+  if (n >= 2 * a.H) return;
+  const bool sem = n >= a.H;
+  const int row = sem ? n - a.H : n, din = sem ? a.din_s : a.din_a;
+  const bf16_t* w = (sem ? a.fc1_s : a.fc1_a) + (int64_t)row * din;
+  const float* x = xin + (sem ? a.din_a : 0);
+  float acc = 0.f;
+  for (int k = 0; k < din; k += 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(w + k);
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc = fmaf(__uint_as_float(u[j] << 16), x[k + 2 * j], acc);
+      acc = fmaf(__uint_as_float(u[j] & 0xffff0000u), x[k + 2 * j + 1], acc);
+    }
+  }
+  a.t[n] = acc + (sem ? a.b1_s : a.b1_a)[row];
+}
+
+template <int KU>       // H = KU * 512
+__global__ __launch_bounds__(256) void conn_fc2_pair_kernel(const ConnPairArgs a, int rows_per_wave) {
+  __shared__ __attribute__((aligned(16))) float ys[2][KU * 512];
+  __shared__ float red[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H;
+  constexpr int NCH = (KU * 128 + 255) / 256;
+  const int nchunks = H >> 2;
+  float4 tv[2][NCH], nv[2][NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = tid + c * 256;
+    const int kk = ch < nchunks ? ch * 4 : 0;
+    tv[0][c] = *reinterpret_cast<const float4*>(a.t + kk);
+    tv[1][c] = *reinterpret_cast<const float4*>(a.t + H + kk);
+    nv[0][c] = *reinterpret_cast<const float4*>(a.nw_a + kk);
+    nv[1][c] = *reinterpret_cast<const float4*>(a.nw_s + kk);
+  }
+  // this wave's rows: gw, gw + nwaves, ... (at most 2 at the shipped shapes); the first row's weights are requested before the prologue
+  const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+  uint4 wa[KU], wsm[KU];
+  auto issue = [&](int row) {
+    const bool live = row < H;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int64_t off = live ? (int64_t)row * H + u * 512 + lane * 8 : 0;
+      wa[u] = *reinterpret_cast<const uint4*>(a.fc2_a + off);
+      wsm[u] = *reinterpret_cast<const uint4*>(a.fc2_s + off);
+    }
+  };
+  issue(gw);
+  float ss[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const float4 v = tv[r][c];
+      s1 += (tid + c * 256 < nchunks) ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
+    }
+    ss[r] = vv_wave_sum(s1);
+  }
+  if (lane == 0) { red[wave][0] = ss[0]; red[wave][1] = ss[1]; }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS-only barrier: the weight loads stay in flight
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const float rs = rsqrtf(((red[0][r] + red[1][r]) + (red[2][r] + red[3][r])) / (float)H + a.eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = tid + c * 256;
+      if (ch < KU * 128) {
+        const float4 v = tv[r][c], w = nv[r][c];
+        *reinterpret_cast<float4*>(&ys[r][ch * 4]) = ch < nchunks ? make_float4(v.x * rs * w.x, v.y * rs * w.y, v.z * rs * w.z, v.w * rs * w.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float ya[KU][8], yb[KU][8];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const float4 p = *reinterpret_cast<const float4*>(&ys[0][u * 512 + lane * 8 + 4 * h2]), q = *reinterpret_cast<const float4*>(&ys[1][u * 512 + lane * 8 + 4 * h2]);
+      ya[u][4 * h2] = p.x; ya[u][4 * h2 + 1] = p.y; ya[u][4 * h2 + 2] = p.z; ya[u][4 * h2 + 3] = p.w;
+      yb[u][4 * h2] = q.x; yb[u][4 * h2 + 1] = q.y; yb[u][4 * h2 + 2] = q.z; yb[u][4 * h2 + 3] = q.w;
+    }
+  }
+  for (int i = 0; i < rows_per_wave; ++i) {
+    const int row = gw + i * nwaves;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const unsigned ua[4] = {wa[u].x, wa[u].y, wa[u].z, wa[u].w}, ub[4] = {wsm[u].x, wsm[u].y, wsm[u].z, wsm[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sa = fmaf(__uint_as_float(ua[j] << 16), ya[u][2 * j], sa); sa = fmaf(__uint_as_float(ua[j] & 0xffff0000u), ya[u][2 * j + 1], sa);
+        sb = fmaf(__uint_as_float(ub[j] << 16), yb[u][2 * j], sb); sb = fmaf(__uint_as_float(ub[j] & 0xffff0000u), yb[u][2 * j + 1], sb);
+      }
+    }
+    if (i + 1 < rows_per_wave) issue(row + nwaves);
+    sa = vv_wave_sum(sa);
+    sb = vv_wave_sum(sb);
+    if (lane == 0 && row < H) {
+      const float v = (sa + a.b2_a[row]) + (sb + a.b2_s[row]);      // acoustic_embed + semantic_embed
+      for (int r = 0; r < a.rows_out; ++r) a.out[(int64_t)r * a.ldo + row] = v;
+    }
+  }
+}
+
 }  // namespace
 
 // internal entry points (vv_common.h)
@@ -636,5 +764,29 @@ int vv_head_modulations_fused(const vv_head* h, const void* c_bf16, int rows, fl
   else hipLaunchKernelGGL((adaln_all_kernel<28, 1>), dim3(total, (rows + 15) / 16), dim3(256), 0, s, c, rows, D, tab);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_modulations_fused: %s", hipGetErrorString(e));
+  return 1;
+}
+
+// 1 = launched, 0 = not covered (caller runs the two connectors one after the other)
+int vv_launch_connector_pair(const vv_connector* ac, const vv_connector* sem, const float* latent, const float* semfeat, float* out, int64_t ldo, int rows_out,
+                             float* ws, hipStream_t s) {
+  const int H = ac->hidden;
+  if (ac->wdt != VV_BF16 || sem->wdt != VV_BF16 || sem->hidden != H || H % 512 || H / 512 > 7 || ac->din % 8 || sem->din % 8 || ac->din + sem->din > 512) return 0;
+  auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
+  if (!a16(ac->fc1) || !a16(sem->fc1) || !a16(ac->fc2) || !a16(sem->fc2) || !a16(ac->norm_w) || !a16(sem->norm_w) || !a16(ws) || !ac->b1 || !sem->b1 || !ac->b2 || !sem->b2) return 0;
+  ConnPairArgs a;
+  a.fc1_a = (const bf16_t*)ac->fc1; a.b1_a = ac->b1; a.din_a = ac->din; a.fc1_s = (const bf16_t*)sem->fc1; a.b1_s = sem->b1; a.din_s = sem->din;
+  a.xa = latent; a.xs = semfeat; a.t = ws;
+  a.nw_a = ac->norm_w; a.nw_s = sem->norm_w; a.fc2_a = (const bf16_t*)ac->fc2; a.fc2_s = (const bf16_t*)sem->fc2; a.b2_a = ac->b2; a.b2_s = sem->b2;
+  a.out = out; a.ldo = ldo; a.rows_out = rows_out; a.H = H; a.eps = 1e-6f;
+  hipLaunchKernelGGL(conn_fc1_pair_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, s, a);
+  const int blocks = 192, nwaves = blocks * 4, rpw = (H + nwaves - 1) / nwaves;
+  switch (H / 512) {
+#define VV_C2(KU) case KU: hipLaunchKernelGGL((conn_fc2_pair_kernel<KU>), dim3(blocks), dim3(256), 0, s, a, rpw); break;
+    VV_C2(1) VV_C2(2) VV_C2(3) VV_C2(4) VV_C2(5) VV_C2(6) VV_C2(7)
+#undef VV_C2
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_connector_pair: %s", hipGetErrorString(e));
   return 1;
 }

@@ -692,6 +692,19 @@ extern "C" int vv_connector_forward(const vv_connector* c, const float* x, int R
   return vv_linear(&a, stream);
 }
 
+// acoustic + semantic connector of ONE frame, summed, stored to rows 0 .. rows_out - 1 of out (the next step's input embedding of the positive
+// and the negative branch are the same vector, modeling_vibevoice_inference.py:665-673).  ws: 2 * hidden floats.
+extern "C" int vv_connector_pair(const vv_connector* ac, const vv_connector* sem, const float* latent, const float* semfeat, float* out, int64_t ldo,
+                                 int rows_out, float* ws, vv_stream_t stream) {
+  if (!ac || !sem || !latent || !semfeat || !out || !ws || rows_out < 1) return vv_set_error(VV_E_ARG, "vv_connector_pair: bad args");
+  const int one = vv_launch_connector_pair(ac, sem, latent, semfeat, out, ldo, rows_out, ws, (hipStream_t)stream);
+  if (one) return one < 0 ? one : 0;
+  VV_TRY(vv_connector_forward(ac, latent, 1, out, 0, ws, stream));
+  VV_TRY(vv_connector_forward(sem, semfeat, 1, out, 1, ws, stream));
+  for (int r = 1; r < rows_out; ++r) VV_TRY(vv_copy_rows(out, 0, out + r * ldo, ldo, 1, ac->hidden, stream));
+  return 0;
+}
+
 extern "C" size_t vv_sizeof(const char* name) {
   if (!name) return 0;
 #define S(t) if (!strcmp(name, #t)) return sizeof(t);

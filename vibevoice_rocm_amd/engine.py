@@ -293,11 +293,8 @@ class Engine:
                                         self.wav.data_ptr(), self._dec_ws.data_ptr(), self.sp), "vv_decoder_forward")
         self._ck(lib.vv_encoder_forward(C.byref(w.sem), self.wav.data_ptr(), cfg.hop, self.sem.data_ptr(),
                                         self._sem_ws.data_ptr(), self.sp), "vv_encoder_forward")
-        self._ck(lib.vv_connector_forward(C.byref(w.ac_conn), self.latent.data_ptr(), 1, self.x2.data_ptr(), 0,
-                                          self.conn_ws.data_ptr(), self.sp), "acoustic_connector")
-        self._ck(lib.vv_connector_forward(C.byref(w.sem_conn), self.sem.data_ptr(), 1, self.x2.data_ptr(), 1,
-                                          self.conn_ws.data_ptr(), self.sp), "semantic_connector")
-        self._ck(lib.vv_copy_rows(self.x2.data_ptr(), 0, self.x2.data_ptr() + 4 * cfg.hidden, cfg.hidden, 1, cfg.hidden, self.sp), "copy")
+        self._ck(lib.vv_connector_pair(C.byref(w.ac_conn), C.byref(w.sem_conn), self.latent.data_ptr(), self.sem.data_ptr(), self.x2.data_ptr(), cfg.hidden, 2,
+                                       self.conn_ws.data_ptr(), self.sp), "connectors")
 
     def _seq_C(self):
         """next embedding = embed_tokens[token] for both rows (modeling_vibevoice_inference.py:567)."""
@@ -468,17 +465,45 @@ class Engine:
     # ---------------------------------------------------------------------------------------------------------
     # voice-prompt path (runs once per utterance)
     # ---------------------------------------------------------------------------------------------------------
-    def acoustic_encode(self, wav: torch.Tensor) -> torch.Tensor:
-        """Whole-utterance (non-streaming) acoustic encoder: wav [T] -> mean latents [ceil(T/hop), vae_dim]."""
+    def acoustic_encode(self, wav: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+        """Whole-utterance (non-streaming) acoustic encoder: wav [T] -> mean latents [ceil(T/hop), vae_dim].  `stream`: run on another HIP
+        stream (the encoder of a voice prompt is stateless: the voices of a dialogue encode concurrently, see acoustic_encode_many)."""
         T = wav.shape[0]
         F = (T + self.cfg.hop - 1) // self.cfg.hop
-        with torch.cuda.stream(self.stream):
+        st = stream or self.stream
+        with torch.cuda.stream(st):
             x = wav.to(device=self.device, dtype=torch.float32).contiguous()
             ws = torch.empty(self.lib.vv_convnet_ws_bytes(C.byref(self.w.ac_enc), T, 0), dtype=torch.uint8, device=self.device)
             out = torch.empty(F, self.cfg.ac_dim, dtype=torch.float32, device=self.device)
-            self._ck(self.lib.vv_encoder_forward(C.byref(self.w.ac_enc), x.data_ptr(), T, out.data_ptr(), ws.data_ptr(), self.sp),
+            self._ck(self.lib.vv_encoder_forward(C.byref(self.w.ac_enc), x.data_ptr(), T, out.data_ptr(), ws.data_ptr(), st.cuda_stream),
                      "vv_encoder_forward")
         return out
+
+    def acoustic_encode_many(self, wavs: List[torch.Tensor], max_streams: int = 4) -> List[torch.Tensor]:
+        """The S voice prompts of a dialogue (modeling_vibevoice_inference.py:149-163 encodes them as one padded batch).  Each voice is an
+        independent causal sequence with its own zero left context and its own ragged tail, so they are not stacked into the row
+        dimension of one launch sequence (every conv / mixer would need per-segment halos); instead they run CONCURRENTLY on up to
+        `max_streams` HIP streams over the shared weights: a single voice's late stages (T <= 200 rows) leave most CUs idle and its ~300
+        launches are latency chains, which the other voices' chains fill.  Streams come from the recycle pool (engine.py, _IDLE_STREAMS)."""
+        if len(wavs) <= 1:
+            return [self.acoustic_encode(w) for w in wavs]
+        pool = _IDLE_STREAMS.setdefault(str(self.device), [])
+        n_side = min(max_streams, len(wavs)) - 1
+        side = [pool.pop() if pool else torch.cuda.Stream(self.device) for _ in range(n_side)]
+        streams = [self.stream] + side
+        for st in side:
+            st.wait_stream(self.stream)                     # inputs were produced on / ordered into the engine stream
+        outs = []
+        for i, w in enumerate(wavs):
+            st = streams[i % len(streams)]
+            o = self.acoustic_encode(w, stream=st)
+            if st is not self.stream:
+                o.record_stream(self.stream)
+            outs.append(o)
+        for st in side:
+            self.stream.wait_stream(st)
+            pool.append(st)
+        return outs
 
     def connector(self, which: str, x: torch.Tensor) -> torch.Tensor:
         c = self.w.ac_conn if which == "acoustic" else self.w.sem_conn

@@ -210,14 +210,16 @@ class VibeVoiceForConditionalGenerationInference:
         Fm = speech_masks.shape[1]
         n_frames = speech_masks.sum(-1).tolist()
         means = torch.zeros(S, Fm, cfg.ac_dim, dtype=torch.float32, device=self.device)
-        for i in range(S):
-            # causal encoder: frames < n_frames[i] only see samples < n_frames[i]*hop, so the zero tail of the padded batch
-            # row beyond that boundary never matters; when the boundary exceeds Tmax the reference pads features instead.
-            t_i = min(int(n_frames[i]) * cfg.hop, Tmax)
-            if t_i <= 0:
-                continue
-            m = eng.acoustic_encode(speech_tensors[i, :t_i])
-            means[i, : m.shape[0]] = m
+        # causal encoder: frames < n_frames[i] only see samples < n_frames[i]*hop, so the zero tail of the padded batch
+        # row beyond that boundary never matters; when the boundary exceeds Tmax the reference pads features instead.
+        t_len = [min(int(n_frames[i]) * cfg.hop, Tmax) for i in range(S)]
+        live = [i for i in range(S) if t_len[i] > 0]
+        with torch.cuda.stream(eng.stream):
+            st_dev = speech_tensors.to(self.device)
+        encoded = eng.acoustic_encode_many([st_dev[i, :t_len[i]] for i in live])      # the S voices run concurrently
+        with torch.cuda.stream(eng.stream):
+            for i, m in zip(live, encoded):
+                means[i, : m.shape[0]] = m
         with torch.cuda.stream(eng.stream):
             if cfg.ac_std_dist == "gaussian":
                 if std_noise is None:
