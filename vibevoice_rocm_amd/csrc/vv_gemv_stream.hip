@@ -81,6 +81,7 @@ __device__ __forceinline__ void epi_pre(const vv_lin_args& a, int m, int n, floa
 }
 
 int g_blocks_override = 0;   // tuning hook (vv_tune)
+int g_waves_override = 0;    // tuning hook "gemv_waves": waves per block of the whole-row (KSPLIT == 1) kernels, 3 .. 8
 int g_opt = 13;              // tuning hook "gemv_opt": bit 0 / 1 = batched prologue for RMSNorm / no prologue, bit 2 = straight-line epilogue-operand loads, bit 3 = block-staged RMSNorm prologue (KSPLIT == 1)
 int g_long_cap = 512;        // persistent blocks for K-split launches with K > 6144 (tuning hook)
 int g_long_ku = 5;           // K units per wave allowed for rows longer than 12 units (tuning hook: 3 -> 8 waves split K)
@@ -500,8 +501,8 @@ void launch_rw(const vv_lin_args& a, hipStream_t s) {
   // wave-per-row layout (more blocks only add prologue copies and a ragged last round), one block per row group when the
   // block's waves split K
   const int n_groups = (a.n + RW - 1) / RW;
-  int waves = 4;
-  const int work = (KSPLIT == 1) ? (n_groups + 3) / 4 : n_groups;       // blocks if each wave did exactly one group
+  const int waves = (KSPLIT == 1 && g_waves_override >= 3 && g_waves_override <= 8) ? g_waves_override : 4;
+  const int work = (KSPLIT == 1) ? (n_groups + waves - 1) / waves : n_groups;       // blocks if each wave did exactly one group
   // K split: every block reads all of x (M x K fp32 from L2); beyond ~6K columns that traffic rivals the weights, so long
   // rows use fewer, persistent blocks (n=1536 k=8960: 10.4 us at 768 blocks, 9.1 us at 512)
   const int cap = (KSPLIT == 1) ? (DUAL ? (RW == 1 ? 512 : 448) : 512) : (a.k > 6144 ? g_long_cap : 1024);
@@ -566,6 +567,7 @@ bool launch_m8(const vv_lin_args& a, hipStream_t s, int ksplit, int ku) {
 }  // namespace
 
 void vv_gemv_stream_set_blocks(int b) { g_blocks_override = b; }
+void vv_gemv_stream_set_waves(int w) { g_waves_override = w; }
 void vv_gemv_stream_set_opt(int o) { g_opt = o; }
 void vv_gemv_stream_set_long(int cap, int ku) { if (cap > 0) g_long_cap = cap; if (ku > 0) g_long_ku = ku; }
 void vv_gemv_stream_set_dual_rw(int r) { g_dual_rw = r; }

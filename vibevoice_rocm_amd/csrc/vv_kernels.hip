@@ -39,6 +39,7 @@ extern "C" int vv_init(void) {
   return vv_fused_init();
 }
 void vv_gemv_stream_set_blocks(int b);
+void vv_gemv_stream_set_waves(int w);
 void vv_gemv_stream_set_opt(int o);
 void vv_gemv_stream_set_long(int cap, int ku);
 void vv_gemv_stream_set_dual_rw(int r);
@@ -58,6 +59,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_long_cap")) { vv_gemv_stream_set_long(value, 0); return 0; }
   if (key && !strcmp(key, "gemv_long_ku")) { vv_gemv_stream_set_long(0, value); return 0; }
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
+  if (key && !strcmp(key, "gemv_waves")) { vv_gemv_stream_set_waves(value); return 0; }
   if (key && !strcmp(key, "gemv_opt")) { vv_gemv_stream_set_opt(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
