@@ -507,10 +507,12 @@ def init_ranks(gpus):
     if world != gpus:
         raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (self-launching) or with "
                          f"torch.distributed.run --nproc-per-node N")
-    if world == 1:
+    if world == 1 and os.environ.get("VV_DIST_FORCE") != "1":
         return rank, local_rank, world, None, None
+    # VV_DIST_FORCE=1: a one-rank process group, so that the RCCL branch (broadcast, gather, max-reduce, barrier) runs end to end on a 1-GPU box
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
     backend = os.environ.get("VV_DIST_BACKEND", "nccl")          # "gloo" lets ranks rehearse on one GPU / on the CPU
     if os.environ.get("VV_ALL_RANKS_ONE_GPU") == "1":
         local_rank = 0
@@ -586,7 +588,7 @@ def main():
     # rank 0 owns the (random-init) checkpoint; replicas receive it over RCCL/xGMI
     sd = synth_state_dict_torch(cfg, 1234, device=device, dtype=dtype) if rank == 0 else None
     rccl = None
-    if world > 1:
+    if dist is not None:
         torch.cuda.synchronize()
         dist.barrier()
         tb = time.perf_counter()

@@ -574,3 +574,52 @@ def test_connector_pair_vs_oracle_and_two_calls(preset, dtype):
     e2 = rel_rms(pair[0].cpu().numpy(), two.cpu().numpy(), f"connector pair {preset} {dtype} vs two calls")
     assert e < 1e-5 and e2 < 1e-5, f"connector pair: vs oracle {e:.3e}, vs two calls {e2:.3e}"
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the RCCL code path on real hardware (one rank: all a 1-GPU box can host)
+# ---------------------------------------------------------------------------------------------------------------
+_RCCL_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VV_ROOT"])
+from vibevoice_rocm_amd import distributed as vd
+from vibevoice_rocm_amd.config import VVConfig
+from vibevoice_rocm_amd.synth import synth_state_dict
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+assert dist.get_backend() == "nccl"
+cfg = VVConfig.preset("tiny")
+ref = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 7).items()}
+for mode in ("broadcast", "scatter_allgather"):
+    os.environ["VV_BCAST"] = mode
+    sd = vd.broadcast_state_dict(ref, cfg, torch.bfloat16, "cuda:0", src=0)
+    torch.cuda.synchronize()
+    assert set(sd) == set(ref)
+    for k in ref:
+        want = ref[k].to(torch.bfloat16 if ref[k].dim() >= 2 else torch.float32)
+        assert sd[k].is_cuda and torch.equal(sd[k].cpu(), want), (mode, k)
+got = vd.gather_waveforms(torch.arange(3200, dtype=torch.float32, device="cuda:0")[None], dst=0)
+assert len(got) == 1 and got[0].shape == (1, 3200) and torch.equal(got[0].cpu()[0], torch.arange(3200, dtype=torch.float32))
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t.item()) == 1.5
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_rccl_backend_single_rank_collectives():
+    """`distributed.broadcast_state_dict` (both forms: one broadcast; scatter + all_gather_into_tensor), `gather_waveforms`, the MAX
+    all-reduce and the barrier of bench.py on the REAL backend ("nccl" = RCCL) with the one rank a 1-GPU box can host: catches device /
+    dtype / API mismatches of the RCCL branch that the gloo tests cannot see.  Runs in a child process (its own process group)."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(VV_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33000 + os.getpid() % 1000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
