@@ -498,6 +498,26 @@ def launch_ranks(n, argv, timeout=None):
     return rc
 
 
+_RESULT_OUT = None
+
+
+def claim_stdout():
+    """fd 1 carries the result line and nothing else: native code of the collectives libraries writes to stdout (RCCL prints a five-line
+    version banner at init, gloo its connection notes), so a rank process parks the real stdout, points fd 1 at stderr for everybody
+    else, and emit_result() writes the one JSON line to the parked descriptor."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_result(obj):
+    out = _RESULT_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def init_ranks(gpus):
     """RANK / LOCAL_RANK / WORLD_SIZE from the environment (set by torch.distributed.run or by launch_ranks).  WORLD_SIZE must equal
     --gpus in every case.  Returns (rank, local_rank, world, dist module or None, backend name or None)."""
@@ -533,8 +553,8 @@ def stub_body(args, rank, world, dist, backend):
     if os.environ.get("VV_BENCH_STUB_FAIL_RANK") == str(rank):
         raise SystemExit(3)
     if rank == 0:
-        print(json.dumps({"metric": "stub", "n_gpus": world, "max_rank_plus_1": float(t.item()),
-                          "rccl": {"ranks": dist.get_world_size() if dist is not None else 1, "backend": backend}}), flush=True)
+        emit_result({"metric": "stub", "n_gpus": world, "max_rank_plus_1": float(t.item()),
+                     "rccl": {"ranks": dist.get_world_size() if dist is not None else 1, "backend": backend}})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -572,6 +592,7 @@ def main():
         # `python bench.py --gpus N` by itself: this process has made no GPU call yet (argparse only) and never will - it starts N
         # fresh rank processes, relays rank 0's JSON line and leaves with the worst exit code
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    claim_stdout()
     rank, local_rank, world, dist, backend = init_ranks(args.gpus)
     if os.environ.get("VV_BENCH_STUB") == "1":
         return stub_body(args, rank, world, dist, backend)
@@ -744,7 +765,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline_leg(sd15, cfg15)
         log("cpu baseline done")
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit_result(result)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
