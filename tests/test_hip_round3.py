@@ -623,3 +623,41 @@ def test_rccl_backend_single_rank_collectives():
     env.update(VV_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33000 + os.getpid() % 1000), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_long_context_decode_step_grouped_vs_per_head():
+    """The long-form regime (the reference's 45 - 90 minute dialogues, up to 64K context): a batch-2 Qwen2 decode step on a 65 536-slot
+    bf16 cache holding 50 000 / 17 000 cached keys, with the keys split over workgroups - grouped-query matrix-core attention (64 splits,
+    partials folded by the last workgroup) against the per-head VALU kernel (16 splits) on the same cache, and positions near the tile /
+    split edges.  `mid` shapes (head_dim 128, GQA 2)."""
+    _need_gpu()
+    from conftest import vt_tiles as _vt
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.engine import Engine
+    from vibevoice_rocm_amd.synth import synth_state_dict
+    cfg = VVConfig.preset("mid")
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16).float() for k, v in synth_state_dict(cfg, 11).items()}
+    eng = Engine(cfg, sd, device="cuda:0", dtype=torch.bfloat16, use_graphs=False)
+    eng.begin_sequence(65536, [cfg.vocab - 4, cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    with torch.cuda.stream(eng.stream):
+        k, v = eng._kv_t
+        k.copy_(torch.randn(k.shape, generator=g, device="cuda").to(torch.bfloat16))
+        v.copy_(torch.randn(v.shape, generator=g, device="cuda").to(torch.bfloat16))
+        eng._kv_vt.copy_(_vt(v))
+        x = 0.05 * torch.randn(2, cfg.hidden, generator=g, device="cuda")
+    outs = {}
+    for lens in ((50000, 17000), (1023, 1024), (65535 - 1, 31)):
+        for gqa in (0, 1):
+            eng.lib.vv_tune(b"attn_gqa", gqa)
+            with torch.cuda.stream(eng.stream):
+                eng.x2.copy_(x)
+                eng.lens.copy_(torch.tensor(lens, dtype=torch.int32))
+                eng.llm_forward(eng.x2, eng.lens, None, eng.hidden2)
+            eng.stream.synchronize()
+            outs[(lens, gqa)] = eng.hidden2.cpu().numpy().copy()
+        eng.lib.vv_tune(b"attn_gqa", 1)
+        assert np.isfinite(outs[(lens, 1)]).all()
+        e = rel_rms(outs[(lens, 1)], outs[(lens, 0)], f"long-context decode step lens={lens}: grouped vs per-head attention")
+        assert e < 2e-3, f"lens={lens}: grouped vs per-head decode step rel RMS {e:.3e}"
+    eng.close()

@@ -11,7 +11,8 @@ sd = synth_state_dict_torch(cfg, 1234, device="cuda:0", dtype=torch.bfloat16)
 m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
 m.set_ddpm_inference_steps(20)
 eng = m.engine; lib = eng.lib; V = cfg.vocab
-for S, smax in ((440, 1024), (3600, 4096), (7200, 8192), (12000, 12288), (16000, 16384), (32000, 32768)):
+SWEEP = ((440, 1024), (440, 2048), (1800, 2048), (3600, 4096), (5400, 6144), (7200, 8192), (12000, 12288), (16000, 16384), (32000, 32768)) + (((64000, 65536),) if model == '1.5b' else ())
+for S, smax in SWEEP:
     eng.begin_sequence(smax, [V-4, V-3, V-2, V-1])
     with torch.cuda.stream(eng.stream):
         eng.lens.copy_(torch.tensor([S, S // 3], dtype=torch.int32))

@@ -238,18 +238,29 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const float* qkv, 
     }
   }
   __syncthreads();
-  if (s_last && tid < d) {
-    const float* p0 = part + (((int64_t)r * heads + h) * nsplit) * (d + 2);
-    float MM = -INFINITY;
-    for (int sgi = 0; sgi < nsplit; ++sgi) MM = fmaxf(MM, p0[sgi * (d + 2)]);
-    float nn = 0.f, dn = 0.f;
-    for (int sgi = 0; sgi < nsplit; ++sgi) {
-      const float* ps = p0 + sgi * (d + 2);
-      const float w = ex2(ps[0] - MM);
-      dn = fmaf(w, ps[1], dn);
-      nn = fmaf(w, ps[2 + tid], nn);
-    }
-    out[(int64_t)r * ldo + h * d + tid] = nn / dn;
+  if (!s_last) return;
+  // fold the nsplit partials: (m, den) of every split to LDS, then thread (split quarter, d) sums its quarter of the splits with its loads in
+  // flight together and the quarters meet in LDS (a serial loop of 2 x nsplit dependent loads per output was most of the split path's 3.9 us)
+  float* fm = &sacc[0][0];                                 // [2][nsplit] (m, den), then [NW / 2][d] quarter sums
+  const float* p0 = part + (((int64_t)r * heads + h) * nsplit) * (d + 2);
+  if (tid < nsplit) { fm[tid] = p0[tid * (d + 2)]; fm[nsplit + tid] = p0[tid * (d + 2) + 1]; }
+  __syncthreads();
+  float MM = -INFINITY;
+  for (int sgi = 0; sgi < nsplit; ++sgi) MM = fmaxf(MM, fm[sgi]);
+  constexpr int NQ = NW / 2;                               // NW * 64 threads = NQ quarters x 128 d
+  const int dq = tid & (d - 1), sq = tid >> 7;
+  float nn = 0.f;
+#pragma unroll 4
+  for (int sgi = sq; sgi < nsplit; sgi += NQ) nn = fmaf(ex2(fm[sgi] - MM), p0[sgi * (d + 2) + 2 + dq], nn);     // an empty split has m = -inf: weight 0, num 0
+  float* qs = fm + 2 * nsplit;
+  qs[sq * d + dq] = nn;
+  __syncthreads();
+  if (tid < d) {
+    float dn = 0.f, tot = 0.f;
+    for (int sgi = 0; sgi < nsplit; ++sgi) dn = fmaf(ex2(fm[sgi] - MM), fm[nsplit + sgi], dn);
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) tot += qs[qq * d + tid];
+    out[(int64_t)r * ldo + h * d + tid] = tot / dn;
   }
 }
 
@@ -518,20 +529,45 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   }
   __syncthreads();
   if (!s_last) return;
-  for (int o = tid; o < G * d; o += NW * 64) {
-    const int qh = o >> 7, dd = o & 127;
-    const float* p0 = part + (((int64_t)r * heads + kvh * G + qh) * nsplit) * (d + 2);
+  // the last workgroup folds nsplit x G partials (up to 200 KB): (m, den) of every (head, split) go to LDS first, then thread (split quarter, d)
+  // sums its quarter of the splits with 8 loads in flight and the four quarters meet in LDS - a serial loop of dependent loads over 64
+  // splits cost more than the attention itself (1.5B, S = 16 000: 2.07 -> 3.56 ms per LLM step)
+  float* sm = &so[0][0][0];                               // [2][G * nsplit] (m, den), then [4][G * d] quarter sums behind them
+  const int gn = G * nsplit;
+  for (int i = tid; i < gn; i += NW * 64) {
+    const int qh = i / nsplit, sg = i - qh * nsplit;
+    const float* pq = part + ((((int64_t)r * heads + kvh * G + qh) * nsplit) + sg) * (d + 2);
+    sm[i] = pq[0];
+    sm[gn + i] = pq[1];
+  }
+  __syncthreads();
+  float* qsum = sm + 2 * gn;                              // [4][G][d]
+  const int dd = tid & 127, sq = tid >> 7;                // NW * 64 = 512 threads: 4 split quarters x 128 d
+  for (int qh = 0; qh < G; ++qh) {
     float MM = -INFINITY;
-    for (int sg = 0; sg < nsplit; ++sg) MM = fmaxf(MM, p0[sg * (d + 2)]);
-    float nn = 0.f, dn = 0.f;
-    for (int sg = 0; sg < nsplit; ++sg) {
-      const float* ps = p0 + sg * (d + 2);
-      if (ps[0] == -INFINITY) continue;                 // a split without keys
-      const float w = ex2(ps[0] - MM);
-      dn = fmaf(w, ps[1], dn);
-      nn = fmaf(w, ps[2 + dd], nn);
+    for (int sg = 0; sg < nsplit; ++sg) MM = fmaxf(MM, sm[qh * nsplit + sg]);
+    const float* p0 = part + (((int64_t)r * heads + kvh * G + qh) * nsplit) * (d + 2) + 2 + dd;
+    float nn = 0.f;
+#pragma unroll 8
+    for (int sg = sq; sg < nsplit; sg += 4) {
+      const float mv = sm[qh * nsplit + sg];
+      const float w = mv == -INFINITY ? 0.f : ex2(mv - MM);      // a split without keys
+      nn = fmaf(w, p0[(int64_t)sg * (d + 2)], nn);
     }
-    out[(int64_t)r * ldo + (int64_t)(kvh * G + qh) * d + dd] = nn / dn;
+    qsum[(sq * G + qh) * d + dd] = nn;
+  }
+  __syncthreads();
+  for (int o = tid; o < G * d; o += NW * 64) {
+    const int qh = o >> 7, d2 = o & 127;
+    float MM = -INFINITY;
+    for (int sg = 0; sg < nsplit; ++sg) MM = fmaxf(MM, sm[qh * nsplit + sg]);
+    float dn = 0.f;
+    for (int sg = 0; sg < nsplit; ++sg) {
+      const float mv = sm[qh * nsplit + sg];
+      dn = fmaf(mv == -INFINITY ? 0.f : ex2(mv - MM), sm[gn + qh * nsplit + sg], dn);
+    }
+    const float nn = (qsum[(0 * G + qh) * d + d2] + qsum[(1 * G + qh) * d + d2]) + (qsum[(2 * G + qh) * d + d2] + qsum[(3 * G + qh) * d + d2]);
+    out[(int64_t)r * ldo + (int64_t)(kvh * G + qh) * d + d2] = nn / dn;
   }
 }
 
@@ -541,20 +577,29 @@ int g_gqa = 1;     // tuning hook "attn_gqa"
 
 // 1 launched, 0 not covered (caller falls back to the generic kernel), < 0 error.  part / tickets: split-key workspace or null (nsplit = 1)
 int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float2* rope, const int* lens, float* out,
-                          int64_t ldo, float* part, int* tickets, int nsplit, hipStream_t s) {
+                          int64_t ldo, float* part, int* tickets, int nsplit, int part_cap, hipStream_t s) {
   if (kv->kvdt != VV_BF16 || kv->head_dim != 128) return 0;
   if (((uintptr_t)qkv % 16) || (ld_qkv % 4) || ((uintptr_t)rope % 16) || ((uintptr_t)kv->k % 16) || ((uintptr_t)kv->v % 16)) return 0;
   if (!part || !tickets || nsplit < 1) nsplit = 1;
   if (nsplit > 16) nsplit = 16;
   const int G = heads / kv->kv_heads;
-  // The grouped kernel pays in the long-form regime (the reference's 45 - 90 minute dialogues: 32K - 64K contexts), where K / V bytes set the
-  // time: one K / V pass per KV head instead of one per q head.  Measured LLM step, per-head -> grouped (tools/mb_attn_long.py, MI355X):
-  // 7B S = 7 200: 4.46 -> 3.88 ms, S = 32 000: 6.39 -> 4.43 ms; 1.5B S = 16 000: 2.16 -> 2.07 ms, S = 32 000: 2.79 -> 2.41 ms.  Below
-  // ~24K cached key rows per (layer, cache row) its few workgroups pull a (row, KV head)'s whole cache through one CU's address path
-  // (16 -> 12 us per layer at S = 370 against 7.4 us for the per-head kernel's 24 workgroups; phase timing: tools/convffn_phase.py attn 2),
-  // so short contexts keep the per-head kernel.  g_gqa (tuning hook "attn_gqa"): 1 = by that rule, 2 = always, 0 = never.
-  if (g_gqa && ((nsplit > 1 && (long)kv->kv_heads * kv->s_max >= 24576) || g_gqa == 2) && kv->vt && G <= GQ_MAXG && kv->s_max % 32 == 0 && kv->s_max >= 64 && ((uintptr_t)kv->vt % 8) == 0) {
-    hipLaunchKernelGGL((attn_decode_gqa_kernel<8>), dim3(kv->kv_heads, R, nsplit), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
+  // The grouped kernel pays where K / V bytes set the time - the long-form regime (the reference's 45 - 90 minute dialogues: 32K - 64K contexts) and,
+  // with 7 q heads per KV head, from ~3K keys on: one K / V pass per KV head instead of one per q head.  Measured LLM step, per-head -> grouped
+  // (tools/mb_attn_long.py, MI355X, profiles/r03_attn_long_context.txt): 7B S = 3 600: 3.67 -> 3.52 ms, S = 7 200: 4.36 -> 3.74, S = 32 000:
+  // 6.23 -> 4.23 ms; 1.5B S = 12 000: 1.88 -> 1.79, S = 32 000: 2.64 -> 2.01, S = 64 000: 3.90 -> 2.59 ms.  Below that its few workgroups pull a
+  // (row, KV head)'s whole cache through one CU's address path (12 us per layer at S = 370 against 7.4 us for the per-head kernel's 24
+  // workgroups; phase timing: tools/convffn_phase.py attn 2), so short contexts keep the per-head kernel.
+  // g_gqa (tuning hook "attn_gqa"): 1 = by that rule, 2 = always, 0 = never.
+  const long gqa_min = (G >= 7) ? 12288 : 24576;          // cached key rows per (layer, cache row): kv_heads x s_max
+  if (g_gqa && ((nsplit > 1 && (long)kv->kv_heads * kv->s_max >= gqa_min) || g_gqa == 2) && kv->vt && G <= GQ_MAXG && kv->s_max % 32 == 0 && kv->s_max >= 64 && ((uintptr_t)kv->vt % 8) == 0) {
+    // very long contexts: more splits than the per-head kernel's 16, so that a workgroup pulls ~0.5 MB through its CU instead of megabytes
+    // (4 - 8 (row, KV head) pairs x 16 splits leave three quarters of the chip idle: 68 us per layer at S = 64 000)
+    int ng = nsplit;
+    if (nsplit > 1) {                                   // ~1024 keys (0.5 MB of K / V) per split once the per-head kernel's 16 splits exceed that
+      if (kv->s_max / 1024 > ng) ng = kv->s_max / 1024;
+      if (ng > part_cap) ng = part_cap;
+    }
+    hipLaunchKernelGGL((attn_decode_gqa_kernel<8>), dim3(kv->kv_heads, R, ng), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_attn_decode (gqa): %s", hipGetErrorString(e));
     return 1;

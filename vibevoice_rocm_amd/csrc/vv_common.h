@@ -24,10 +24,11 @@ int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_str
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
 int vv_mfma_gemm_init();
 // vv_attn_decode.hip: bf16 KV cache, head_dim 128; part / tickets = split-key workspace ([R, heads, nsplit, 130] floats, [R, heads] zeroed ints) or null
+// part_cap: splits the partials workspace has room for (>= nsplit); the grouped kernel may use more splits than the per-head kernel's nsplit
 int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float2* rope, const int* lens, float* out,
-                          int64_t ldo, float* part, int* tickets, int nsplit, hipStream_t s);
+                          int64_t ldo, float* part, int* tickets, int nsplit, int part_cap, hipStream_t s);
 int vv_attn_decode_ws(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table, const int* lens, float* out,
-                      int64_t ldo, float* part, int* tickets, int nsplit, vv_stream_t stream);
+                      int64_t ldo, float* part, int* tickets, int nsplit, int part_cap, vv_stream_t stream);
 // vv_attn_prefill.hip: matrix-core prompt attention (bf16 cache + kv->vt, head_dim 128); 1 launched, 0 not covered, < 0 error
 int vv_launch_attn_prefill(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const int* lens, const int* cache_rows,
                            float* out, int64_t ldo, hipStream_t s);

@@ -1110,11 +1110,11 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(const float* qkv, int6
 
 extern "C" int vv_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table,
                               const int* lens, float* out, int64_t ldo, vv_stream_t stream) {
-  return vv_attn_decode_ws(qkv, ld_qkv, R, heads, kv, layer, rope_table, lens, out, ldo, nullptr, nullptr, 1, stream);
+  return vv_attn_decode_ws(qkv, ld_qkv, R, heads, kv, layer, rope_table, lens, out, ldo, nullptr, nullptr, 1, 1, stream);
 }
 
 int vv_attn_decode_ws(const float* qkv, int64_t ld_qkv, int R, int heads, const vv_kv* kv, int layer, const float* rope_table, const int* lens, float* out,
-                      int64_t ldo, float* part, int* tickets, int nsplit, vv_stream_t stream) {
+                      int64_t ldo, float* part, int* tickets, int nsplit, int part_cap, vv_stream_t stream) {
   const float2* inv_freq = reinterpret_cast<const float2*>(rope_table);
   if (!qkv || !kv || !lens || !out || !inv_freq) return vv_set_error(VV_E_ARG, "vv_attn_decode: null pointer");
   if (layer < 0 || layer >= kv->layers || R <= 0 || R > kv->rows || heads % kv->kv_heads) return vv_set_error(VV_E_ARG, "vv_attn_decode: bad layer/R/heads");
@@ -1125,7 +1125,7 @@ int vv_attn_decode_ws(const float* qkv, int64_t ld_qkv, int R, int heads, const 
   if (lds > 65536) return vv_set_error(VV_E_UNSUPPORTED, "vv_attn_decode: LDS %zu too large", lds);
   hipStream_t s = (hipStream_t)stream;
   {   // the product shape (bf16 cache, head_dim 128): vv_attn_decode.hip
-    const int rc = vv_launch_attn_decode(qkv, ld_qkv, R, heads, kv, layer, inv_freq, lens, out, ldo, part, tickets, nsplit, s);
+    const int rc = vv_launch_attn_decode(qkv, ld_qkv, R, heads, kv, layer, inv_freq, lens, out, ldo, part, tickets, nsplit, part_cap, s);
     if (rc) return rc < 0 ? rc : 0;
   }
   dim3 grid(heads, R);

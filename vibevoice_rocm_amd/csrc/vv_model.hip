@@ -45,7 +45,8 @@ static inline void use_w8(vv_lin_args& a, const vv_w8& q, const vv_w8* q2 = null
 #define VV_PREFILL_ROWS 64
 // decode attention over long contexts splits the keys over up to this many blocks per (row, q head) (vv_attn_decode.hip)
 #define VV_ATT_ROWS 8
-#define VV_ATT_MAX_SPLIT 16
+#define VV_ATT_MAX_SPLIT 16        // per-head kernel
+#define VV_ATT_PART_SPLITS 64      // capacity of the partials workspace: the grouped kernel spreads long contexts over up to 64 splits per (row, KV head)
 
 extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   if (!m || R <= 0) return 0;
@@ -53,7 +54,7 @@ extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   const size_t widest = (size_t)(m->inter > m->hidden ? m->inter : m->hidden);
   return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter) +
          al((size_t)R * m->head_dim) + (R >= VV_PREFILL_ROWS ? al((size_t)R * widest / 2 + 64) : 0) +
-         al((size_t)VV_ATT_ROWS * m->heads * VV_ATT_MAX_SPLIT * (m->head_dim + 2)) + al((size_t)VV_ATT_ROWS * m->heads);   // split-key decode attention
+         al((size_t)VV_ATT_ROWS * m->heads * VV_ATT_PART_SPLITS * (m->head_dim + 2)) + al((size_t)VV_ATT_ROWS * m->heads);   // split-key decode attention
 }
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
@@ -76,7 +77,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   VV_TRY(vv_rope_table(lens, m->inv_freq, R, d, rope, stream));
   const bool prefill = (R >= VV_PREFILL_ROWS) && m->wdt == VV_BF16 && H % 16 == 0 && m->inter % 16 == 0 && qd % 16 == 0;
   void* xb = prefill ? (void*)c.take((size_t)R * (m->inter > H ? m->inter : H) / 2 + 64) : nullptr;
-  float* att_part = c.take((size_t)VV_ATT_ROWS * m->heads * VV_ATT_MAX_SPLIT * (d + 2));
+  float* att_part = c.take((size_t)VV_ATT_ROWS * m->heads * VV_ATT_PART_SPLITS * (d + 2));
   int* att_tickets = reinterpret_cast<int*>(c.take((size_t)VV_ATT_ROWS * m->heads));
   // contexts beyond ~1K keys: one block per (row, q head) would pull all of its K / V through a single CU (~95 GB/s: 8 us at S = 3000)
   const bool decode = (cache_rows == nullptr && R <= kv->rows);
@@ -102,7 +103,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     }
     VV_TRY(vv_linear(&a, stream));
     if (decode) {
-      VV_TRY(vv_attn_decode_ws(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, att_part, att_tickets, att_split, stream));   // decode: RoPE + append fused
+      VV_TRY(vv_attn_decode_ws(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, att_part, att_tickets, att_split, VV_ATT_PART_SPLITS, stream));   // decode: RoPE + append fused
     } else {
       VV_TRY(vv_rope_store(qkv, qkvd, R, m->heads, kv, l, rope, lens, cache_rows, stream));
       VV_TRY(vv_attn(qkv, qkvd, R, m->heads, kv, l, lens, cache_rows, att, qd, stream));
