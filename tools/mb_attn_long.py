@@ -17,8 +17,9 @@ for S, smax in SWEEP:
     with torch.cuda.stream(eng.stream):
         eng.lens.copy_(torch.tensor([S, S // 3], dtype=torch.int32))
     res = []
-    for gqa in (0, 1, 2):
-        lib.vv_tune(b"attn_gqa", gqa)
+    for gqa in (0, 1, 2) if len(sys.argv) < 3 else (1, 1001, 1002):     # argv[2] = "keys": grouped kernel at 1024 / 512 / 256 keys per split
+        lib.vv_tune(b"attn_gqa", 1 if gqa > 2 else gqa)
+        lib.vv_tune(b"attn_gqa_keys", {1: 1024, 1001: 512, 1002: 256}.get(gqa, 1024))
         with torch.cuda.stream(eng.stream):
             lens0 = eng.lens.clone()
             L.check(lib.vv_graph_begin(eng.sp), "b"); eng._seq_A(V-4, V-2); ge = C.c_void_p(); L.check(lib.vv_graph_end(eng.sp, C.byref(ge)), "e")
@@ -33,3 +34,4 @@ for S, smax in SWEEP:
             lib.vv_graph_destroy(ge)
     print(f"{model} S={S} s_max={eng.kv.s_max}: LLM step per-head {res[0]:.3f} ms, grouped(split only) {res[1]:.3f} ms, grouped(always) {res[2]:.3f} ms", flush=True)
 lib.vv_tune(b"attn_gqa", 1)
+lib.vv_tune(b"attn_gqa_keys", 1024)

@@ -571,6 +571,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   }
 }
 
+int g_gqa_keys = 1024;   // tuning hook "attn_gqa_keys": cached keys per split of the grouped kernel at long contexts
 int g_gqa = 1;     // tuning hook "attn_gqa"
 
 }  // namespace
@@ -595,9 +596,10 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
     // very long contexts: more splits than the per-head kernel's 16, so that a workgroup pulls ~0.5 MB through its CU instead of megabytes
     // (4 - 8 (row, KV head) pairs x 16 splits leave three quarters of the chip idle: 68 us per layer at S = 64 000)
     int ng = nsplit;
-    if (nsplit > 1) {                                   // ~1024 keys (0.5 MB of K / V) per split once the per-head kernel's 16 splits exceed that
-      if (kv->s_max / 1024 > ng) ng = kv->s_max / 1024;
+    if (nsplit > 1) {                                   // ~g_gqa_keys keys per split once the per-head kernel's 16 splits exceed that
+      if (kv->s_max / g_gqa_keys > ng) ng = kv->s_max / g_gqa_keys;
       if (ng > part_cap) ng = part_cap;
+      if (ng > 128) ng = 128;                           // the merge buffer in LDS holds (m, den) of 8 heads x 128 splits + the quarter sums
     }
     hipLaunchKernelGGL((attn_decode_gqa_kernel<8>), dim3(kv->kv_heads, R, ng), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
     hipError_t e = hipGetLastError();
@@ -611,6 +613,7 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
 }
 
 void vv_attn_decode_set_gqa(int on) { g_gqa = on; }
+void vv_attn_decode_set_gqa_keys(int k) { if (k >= 256) g_gqa_keys = k; }
 
 #ifdef VV_CF_TIMING
 extern "C" int vv_attn_debug_times(unsigned long long* out8, int reset) {

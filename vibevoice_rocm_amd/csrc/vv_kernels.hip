@@ -55,6 +55,7 @@ void vv_mixer_set_rows(int on);
 void vv_mfma_set_mt_prefill(int mt);
 extern int g_attn_group;
 void vv_attn_decode_set_gqa(int on);
+void vv_attn_decode_set_gqa_keys(int k);
 extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks (not part of the stable ABI surface)
   if (key && !strcmp(key, "gemv_long_cap")) { vv_gemv_stream_set_long(value, 0); return 0; }
   if (key && !strcmp(key, "gemv_long_ku")) { vv_gemv_stream_set_long(0, value); return 0; }
@@ -79,6 +80,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "mfma_tiled_bk128")) { vv_mfma_set_tiled_bk128(value); return 0; }
   if (key && !strcmp(key, "attn_group")) { g_attn_group = value; return 0; }
   if (key && !strcmp(key, "attn_gqa")) { vv_attn_decode_set_gqa(value); return 0; }
+  if (key && !strcmp(key, "attn_gqa_keys")) { vv_attn_decode_set_gqa_keys(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_k")) { vv_mfma_set_tiled_small_k(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_dual_bk64")) { vv_mfma_set_tiled_dual_bk64(value); return 0; }
   if (key && !strcmp(key, "mfma_tiled_small_dual")) { vv_mfma_set_tiled_small_dual(value); return 0; }

@@ -46,7 +46,7 @@ static inline void use_w8(vv_lin_args& a, const vv_w8& q, const vv_w8* q2 = null
 // decode attention over long contexts splits the keys over up to this many blocks per (row, q head) (vv_attn_decode.hip)
 #define VV_ATT_ROWS 8
 #define VV_ATT_MAX_SPLIT 16        // per-head kernel
-#define VV_ATT_PART_SPLITS 64      // capacity of the partials workspace: the grouped kernel spreads long contexts over up to 64 splits per (row, KV head)
+#define VV_ATT_PART_SPLITS 128     // capacity of the partials workspace: the grouped kernel spreads long contexts over up to 128 splits per (row, KV head)
 
 extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   if (!m || R <= 0) return 0;
