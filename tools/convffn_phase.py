@@ -86,6 +86,43 @@ def run_narrow():
         print(f"block1d C={C_} T={T}: " + "  ".join(f"{nm} {v:6.0f} ns" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us", flush=True)
 
 
+def run_attn_split():
+    """phase stamps of workgroup (0, 0, 0) of the grouped decode attention on its split-key path (through an Engine's batch-2 decode step)"""
+    import torch
+    sys.path.insert(0, ROOT)
+    from vibevoice_rocm_amd import _lib as L
+    L.LIB_PATH = SO                      # the debug build (stamps compiled in) instead of the product library
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.engine import Engine
+    from vibevoice_rocm_amd.synth import synth_state_dict_torch
+    cfg = VVConfig.preset("1.5b")
+    sd = synth_state_dict_torch(cfg, 1, device="cuda:0", dtype=torch.bfloat16)
+    eng = Engine(cfg, sd, device="cuda:0", dtype=torch.bfloat16, use_graphs=False)
+    lib = eng.lib
+    V = cfg.vocab
+    for S, smax in ((440, 4096), (12000, 12288), (32000, 32768), (64000, 65536)):
+        eng.begin_sequence(smax, [V - 4, V - 3, V - 2, V - 1])
+        lib.vv_tune(b"attn_gqa", 2)
+        t = (C.c_ulonglong * 8)()
+        def step():
+            with torch.cuda.stream(eng.stream):
+                eng.lens.copy_(torch.tensor([S, S // 3], dtype=torch.int32))
+                eng.llm_forward(eng.x2, eng.lens, None, eng.hidden2)
+        for _ in range(3):
+            step()
+        eng.stream.synchronize()
+        dbg = C.CDLL(SO).vv_attn_debug_times
+        dbg(t, 1)
+        n = 10
+        for _ in range(n):
+            step()
+        eng.stream.synchronize()
+        dbg(t, 1)
+        names = ["requests+pos", "rope+split+new token", "key tiles", "LDS+barrier", "merge+partials", "fence+ticket", "final fold"]
+        ns = [t[i] * 10.0 / (n * cfg.layers) for i in range(7)]
+        print(f"grouped split S={S} s_max={smax}: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, ns)) + f"   total {sum(ns) / 1e3:.2f} us (workgroup 0,0,0)", flush=True)
+
+
 def run_gemv():
     import torch
     sys.path.insert(0, ROOT)
@@ -169,6 +206,9 @@ def run_attn(gqa=0):
 if __name__ == "__main__":
     if sys.argv[1:2] == ["attn"]:
         run_attn(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        sys.exit(0)
+    if sys.argv[1:] == ["attn_split"]:
+        run_attn_split()
         sys.exit(0)
     if sys.argv[1:] == ["gemv"]:
         run_gemv()

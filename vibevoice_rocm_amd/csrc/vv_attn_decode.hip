@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 
 #include "vv_hip.h"
 #include "vv_common.h"
@@ -528,6 +529,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     }
   }
   __syncthreads();
+  ASTAMP(5);                                       // partials out, release fence, ticket
   if (!s_last) return;
   // the last workgroup folds nsplit x G partials (up to 200 KB): (m, den) of every (head, split) go to LDS first, then thread (split quarter, d)
   // sums its quarter of the splits with 8 loads in flight and the four quarters meet in LDS - a serial loop of dependent loads over 64
@@ -543,19 +545,38 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
   __syncthreads();
   float* qsum = sm + 2 * gn;                              // [4][G][d]
   const int dd = tid & 127, sq = tid >> 7;                // NW * 64 = 512 threads: 4 split quarters x 128 d
-  for (int qh = 0; qh < G; ++qh) {
-    float MM = -INFINITY;
-    for (int sg = 0; sg < nsplit; ++sg) MM = fmaxf(MM, sm[qh * nsplit + sg]);
-    const float* p0 = part + (((int64_t)r * heads + kvh * G + qh) * nsplit) * (d + 2) + 2 + dd;
-    float nn = 0.f;
-#pragma unroll 8
-    for (int sg = sq; sg < nsplit; sg += 4) {
-      const float mv = sm[qh * nsplit + sg];
-      const float w = mv == -INFINITY ? 0.f : ex2(mv - MM);      // a split without keys
-      nn = fmaf(w, p0[(int64_t)sg * (d + 2)], nn);
+  // ALL of a thread's partial loads (G heads x its quarter of the splits) are requested before any is used: folding head by head put one
+  // round trip to memory per head in a row (8 us at S = 440, tools/convffn_phase.py attn_split).  J = splits per quarter, wave-uniform.
+  auto fold = [&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    float v[GQ_MAXG][J];
+#pragma unroll
+    for (int qh = 0; qh < GQ_MAXG; ++qh) {
+      const float* p0 = part + (((int64_t)r * heads + kvh * G + min(qh, G - 1)) * nsplit) * (d + 2) + 2 + dd;
+#pragma unroll
+      for (int j = 0; j < J; ++j) v[qh][j] = p0[(int64_t)min(sq + 4 * j, nsplit - 1) * (d + 2)];
     }
-    qsum[(sq * G + qh) * d + dd] = nn;
-  }
+#pragma unroll
+    for (int qh = 0; qh < GQ_MAXG; ++qh) {
+      if (qh < G) {
+        float MM = -INFINITY;
+        for (int sg = 0; sg < nsplit; ++sg) MM = fmaxf(MM, sm[qh * nsplit + sg]);
+        float nn = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int sg = sq + 4 * j;
+          const float mv = sg < nsplit ? sm[qh * nsplit + sg] : -INFINITY;
+          nn = fmaf(mv == -INFINITY ? 0.f : ex2(mv - MM), v[qh][j], nn);      // a split without keys (or past nsplit): weight 0
+        }
+        qsum[(sq * G + qh) * d + dd] = nn;
+      }
+    }
+  };
+  const int per_q = (nsplit + 3) >> 2;
+  if (per_q <= 2) fold(std::integral_constant<int, 2>{});
+  else if (per_q <= 4) fold(std::integral_constant<int, 4>{});
+  else if (per_q <= 8) fold(std::integral_constant<int, 8>{});
+  else fold(std::integral_constant<int, 16>{});            // nsplit <= 64 (launcher)
   __syncthreads();
   for (int o = tid; o < G * d; o += NW * 64) {
     const int qh = o >> 7, d2 = o & 127;
@@ -569,6 +590,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_gqa_kernel(const float* q
     const float nn = (qsum[(0 * G + qh) * d + d2] + qsum[(1 * G + qh) * d + d2]) + (qsum[(2 * G + qh) * d + d2] + qsum[(3 * G + qh) * d + d2]);
     out[(int64_t)r * ldo + (int64_t)(kvh * G + qh) * d + d2] = nn / dn;
   }
+  ASTAMP(6);                                       // final fold (last workgroup only)
 }
 
 int g_gqa_keys = 1024;   // tuning hook "attn_gqa_keys": cached keys per split of the grouped kernel at long contexts
@@ -584,14 +606,14 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
   if (!part || !tickets || nsplit < 1) nsplit = 1;
   if (nsplit > 16) nsplit = 16;
   const int G = heads / kv->kv_heads;
-  // The grouped kernel pays where K / V bytes set the time - the long-form regime (the reference's 45 - 90 minute dialogues: 32K - 64K contexts) and,
-  // with 7 q heads per KV head, from ~3K keys on: one K / V pass per KV head instead of one per q head.  Measured LLM step, per-head -> grouped
-  // (tools/mb_attn_long.py, MI355X, profiles/r03_attn_long_context.txt): 7B S = 3 600: 3.67 -> 3.52 ms, S = 7 200: 4.36 -> 3.74, S = 32 000:
-  // 6.23 -> 4.23 ms; 1.5B S = 12 000: 1.88 -> 1.79, S = 32 000: 2.64 -> 2.01, S = 64 000: 3.90 -> 2.59 ms.  Below that its few workgroups pull a
-  // (row, KV head)'s whole cache through one CU's address path (12 us per layer at S = 370 against 7.4 us for the per-head kernel's 24
-  // workgroups; phase timing: tools/convffn_phase.py attn 2), so short contexts keep the per-head kernel.
-  // g_gqa (tuning hook "attn_gqa"): 1 = by that rule, 2 = always, 0 = never.
-  const long gqa_min = (G >= 7) ? 12288 : 24576;          // cached key rows per (layer, cache row): kv_heads x s_max
+  // The grouped kernel pays where K / V bytes set the time - from ~6K cached keys on at 1.5B (2 KV heads), ~3K at 7B (4 KV heads), and most in the
+  // long-form regime (the reference's 45 - 90 minute dialogues: 32K - 64K contexts): one K / V pass per KV head instead of one per q head.
+  // Measured LLM step, per-head -> grouped (tools/mb_attn_long.py, MI355X, profiles/r03_attn_long_context.txt): 7B S = 3 600: 3.67 -> 3.44 ms,
+  // S = 7 200: 4.37 -> 3.59, S = 32 000: 6.21 -> 4.23 ms; 1.5B S = 7 200: 1.68 -> 1.60, S = 16 000: 2.04 -> 1.77, S = 64 000: 3.91 -> 2.65 ms.
+  // Below that its few workgroups pull a (row, KV head)'s whole cache through one CU's address path (12 us per layer at S = 370 against
+  // 7.4 us for the per-head kernel's 24 workgroups; phase timing: tools/convffn_phase.py attn 2 / attn_split), so short contexts keep the
+  // per-head kernel.  g_gqa (tuning hook "attn_gqa"): 1 = by that rule, 2 = always, 0 = never.
+  const long gqa_min = 12288;                              // cached key rows per (layer, cache row): kv_heads x s_max
   if (g_gqa && ((nsplit > 1 && (long)kv->kv_heads * kv->s_max >= gqa_min) || g_gqa == 2) && kv->vt && G <= GQ_MAXG && kv->s_max % 32 == 0 && kv->s_max >= 64 && ((uintptr_t)kv->vt % 8) == 0) {
     // very long contexts: more splits than the per-head kernel's 16, so that a workgroup pulls ~0.5 MB through its CU instead of megabytes
     // (4 - 8 (row, KV head) pairs x 16 splits leave three quarters of the chip idle: 68 us per layer at S = 64 000)
@@ -599,7 +621,7 @@ int vv_launch_attn_decode(const float* qkv, int64_t ld_qkv, int R, int heads, co
     if (nsplit > 1) {                                   // ~g_gqa_keys keys per split once the per-head kernel's 16 splits exceed that
       if (kv->s_max / g_gqa_keys > ng) ng = kv->s_max / g_gqa_keys;
       if (ng > part_cap) ng = part_cap;
-      if (ng > 128) ng = 128;                           // the merge buffer in LDS holds (m, den) of 8 heads x 128 splits + the quarter sums
+      if (ng > 64) ng = 64;                             // the last workgroup folds <= 16 splits per thread quarter with all loads in flight
     }
     hipLaunchKernelGGL((attn_decode_gqa_kernel<8>), dim3(kv->kv_heads, R, ng), dim3(512), 0, s, qkv, ld_qkv, heads, *kv, layer, rope, lens, out, ldo, part, tickets);
     hipError_t e = hipGetLastError();
