@@ -38,6 +38,8 @@ bool vv_head_boundary_supported(const vv_head* h);
 int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
                            const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s);
 int vv_fused_init();
+int vv_head_pre_fused(const vv_head* h, const float* cond2, int64_t ld_cond, const float* temb, int n_steps, void* c_bf16, const float* noise,
+                      float* Xs, float* Ms, float* h0, int64_t ldh, hipStream_t s);   // cond_proj + silu(c0 + temb) rows (bf16) + solver-state init in one launch; 1 launched, 0 not covered
 int vv_launch_connector_pair(const vv_connector* ac, const vv_connector* sem, const float* latent, const float* semfeat, float* out, int64_t ldo, int rows_out,
                              float* ws, hipStream_t s);   // 1 launched, 0 not covered
 int vv_head_modulations_fused(const vv_head* h, const void* c_bf16, int rows, float* const* mod, float* modf, hipStream_t s);   // 1 launched, 0 not covered

@@ -648,6 +648,108 @@ __global__ __launch_bounds__(256) void conn_fc2_pair_kernel(const ConnPairArgs a
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// head_pre_kernel: everything in front of the solver loop that does not need the adaLN matrices, in ONE launch (it was three: the cond_proj
+// GEMV, the silu(c0 + t_emb(t_i)) row expansion, the solver-state initialisation - 4.7 + 5.3 + 4.9 us of a frame for < 1 us of work):
+//   workgroups [0, gemv_blocks): c0 = cond_proj cond for the two CFG rows (a wave owns output pairs n, n + 1), and straight from the wave's
+//                                registers c[(i * 2 + j), n] = bf16(silu(c0[j, n] + temb[i, n])) for every solver step i (lane = step)
+//   the rest:                    X0 = [P noise ; noise], M = 0, both rows of the first step's hidden state (head_init_kernel's body)
+// Reference: modular_vibevoice_diffusion_head.py:262-270 (cond_proj, t_embedder, c = cond + t), :152-156 (SiLU in front of adaLN_modulation).
+// ---------------------------------------------------------------------------------------------------------------
+struct HeadPreArgs {
+  const bf16_t* Wc; const float* cond; int64_t ld_cond; int K;       // cond_proj [D, K], cond [2, K]
+  const float* temb; int n_steps; bf16_t* c_out;                    // temb [n_steps, D] -> c_out [2 n_steps, D]
+  const bf16_t* P; const float* noise; int D, latent; float* Xs; float* Ms; float* h0; int64_t ldh;
+  int gemv_blocks;
+};
+
+template <int KU>      // K = KU * 512
+__global__ __launch_bounds__(256) void head_pre_kernel(const HeadPreArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= a.gemv_blocks) {        // solver-state initialisation
+    __shared__ float nz[256];
+    for (int i = tid; i < a.latent; i += 256) nz[i] = a.noise[i];
+    __syncthreads();
+    const int n = ((int)blockIdx.x - a.gemv_blocks) * 256 + tid;
+    if (n >= a.D + a.latent) return;
+    float s;
+    if (n < a.D) {
+      s = 0.f;
+      const bf16_t* pr = a.P + (int64_t)n * a.latent;
+      for (int j = 0; j < a.latent; ++j) s = fmaf(bf2f(pr[j]), nz[j], s);
+      a.h0[n] = s;
+      a.h0[a.ldh + n] = s;
+    } else {
+      s = nz[n - a.D];
+    }
+    a.Xs[n] = s;
+    a.Ms[n] = 0.f;
+    return;
+  }
+  const int D = a.D, npairs = D >> 1;
+  const int nwaves = a.gemv_blocks * 4;
+  int g = blockIdx.x * 4 + wave;
+  float x[2][KU][8];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const float4 p = *reinterpret_cast<const float4*>(a.cond + r * a.ld_cond + u * 512 + lane * 8), q = *reinterpret_cast<const float4*>(a.cond + r * a.ld_cond + u * 512 + lane * 8 + 4);
+      x[r][u][0] = p.x; x[r][u][1] = p.y; x[r][u][2] = p.z; x[r][u][3] = p.w; x[r][u][4] = q.x; x[r][u][5] = q.y; x[r][u][6] = q.z; x[r][u][7] = q.w;
+    }
+  for (; g < npairs; g += nwaves) {
+    const int n = 2 * g;
+    uint4 w[2][KU];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int u = 0; u < KU; ++u) w[o][u] = *reinterpret_cast<const uint4*>(a.Wc + (int64_t)(n + o) * a.K + u * 512 + lane * 8);
+    // the step rows this lane will write: requested now, they arrive while the dot products run
+    float te[2][2];                                // [pass][output]: steps lane and lane + 64
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int i = min(lane + 64 * ps, a.n_steps - 1);
+      const float2 t2 = *reinterpret_cast<const float2*>(a.temb + (int64_t)i * D + n);
+      te[ps][0] = t2.x; te[ps][1] = t2.y;
+    }
+    float acc[2][2];                               // [output][row]
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      acc[o][0] = 0.f; acc[o][1] = 0.f;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const unsigned uu[4] = {w[o][u].x, w[o][u].y, w[o][u].z, w[o][u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float w0 = __uint_as_float(uu[j] << 16), w1 = __uint_as_float(uu[j] & 0xffff0000u);
+          acc[o][0] = fmaf(w0, x[0][u][2 * j], acc[o][0]); acc[o][0] = fmaf(w1, x[0][u][2 * j + 1], acc[o][0]);
+          acc[o][1] = fmaf(w0, x[1][u][2 * j], acc[o][1]); acc[o][1] = fmaf(w1, x[1][u][2 * j + 1], acc[o][1]);
+        }
+      }
+    }
+    float c0[2][2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) c0[o][r] = vv_wave_sum(acc[o][r]);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int i = lane + 64 * ps;
+      if (i < a.n_steps) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float v0 = c0[0][r] + te[ps][0], v1 = c0[1][r] + te[ps][1];
+          const float s0 = v0 / (1.0f + expf(-v0)), s1 = v1 / (1.0f + expf(-v1));
+          const unsigned u0 = __float_as_uint(s0), u1 = __float_as_uint(s1);        // round to nearest even, as kv_store<bf16_t>
+          const unsigned pk = ((u0 + 0x7fffu + ((u0 >> 16) & 1u)) >> 16) | (((u1 + 0x7fffu + ((u1 >> 16) & 1u)) >> 16) << 16);
+          *reinterpret_cast<unsigned*>(a.c_out + ((int64_t)(i * 2 + r)) * D + n) = pk;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // internal entry points (vv_common.h)
@@ -788,5 +890,27 @@ int vv_launch_connector_pair(const vv_connector* ac, const vv_connector* sem, co
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_connector_pair: %s", hipGetErrorString(e));
+  return 1;
+}
+
+// 1 = launched (cond_proj + silu row expansion + solver-state init), 0 = not covered
+int vv_head_pre_fused(const vv_head* h, const float* cond2, int64_t ld_cond, const float* temb, int n_steps, void* c_bf16, const float* noise,
+                      float* Xs, float* Ms, float* h0, int64_t ldh, hipStream_t s) {
+  const int D = h->D, K = h->cond_dim;
+  if (h->wdt != VV_BF16 || K % 512 || K / 512 > 7 || D % 2 || n_steps > 128 || h->latent > 256) return 0;
+  auto a16 = [](const void* q) { return q && ((uintptr_t)q % 16) == 0; };
+  if (!a16(h->cond_proj) || !a16(cond2) || (ld_cond % 4) || !a16(temb) || !a16(c_bf16) || !h->noisy_proj) return 0;
+  HeadPreArgs a;
+  a.Wc = (const bf16_t*)h->cond_proj; a.cond = cond2; a.ld_cond = ld_cond; a.K = K; a.temb = temb; a.n_steps = n_steps; a.c_out = (bf16_t*)c_bf16;
+  a.P = (const bf16_t*)h->noisy_proj; a.noise = noise; a.D = D; a.latent = h->latent; a.Xs = Xs; a.Ms = Ms; a.h0 = h0; a.ldh = ldh;
+  a.gemv_blocks = 192;
+  const int init_blocks = (D + h->latent + 255) / 256;
+  switch (K / 512) {
+#define VV_HP(KU) case KU: hipLaunchKernelGGL((head_pre_kernel<KU>), dim3(a.gemv_blocks + init_blocks), dim3(256), 0, s, a); break;
+    VV_HP(1) VV_HP(2) VV_HP(3) VV_HP(4) VV_HP(5) VV_HP(6) VV_HP(7)
+#undef VV_HP
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_pre_fused: %s", hipGetErrorString(e));
   return 1;
 }

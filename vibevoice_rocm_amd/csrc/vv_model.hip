@@ -253,11 +253,22 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
   float* Xs = cv.take(D + (size_t)h->latent);
   float* Ms = cv.take(D + (size_t)h->latent);
   // step-invariant work hoisted out of the loop: cond_proj, silu(cond_proj(cond) + t_emb(t_i)), all adaLN modulations
-  vv_lin_args a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
-  VV_TRY(vv_linear(&a, stream));
   const bool cb = h->wdt == VV_BF16 && 2 * n_steps > 8 && D % 32 == 0 && ((uintptr_t)c % 16 == 0);
-  if (cb) VV_TRY(vv_add_rows_silu_bf16(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
-  else VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+  bool ode0 = !sde_noise;
+  for (int i = 0; i < n_steps && ode0; ++i) ode0 = coef[i].cn == 0.f;
+  // the ODE solver on the fused boundary: cond_proj, the row expansion and the solver-state initialisation are one launch (vv_fused.hip)
+  int pre = 0;
+  if (cb && ode0 && vv_head_boundary_supported(h)) {
+    pre = vv_head_pre_fused(h, cond2, ld_cond, temb, n_steps, c, noise, Xs, Ms, hcur, D, s);
+    if (pre < 0) return pre;
+  }
+  vv_lin_args a;
+  if (!pre) {
+    a = lin_base(cond2, ld_cond, 2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
+    VV_TRY(vv_linear(&a, stream));
+    if (cb) VV_TRY(vv_add_rows_silu_bf16(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+    else VV_TRY(vv_add_rows_silu(c0, D, temb, D, c, 2 * n_steps, 2, D, stream));
+  }
   VV_TRY(head_modulations(h, c, 2 * n_steps, mod, modf, true, cb, stream));
   bool ode = !sde_noise;
   for (int i = 0; i < n_steps && ode; ++i) ode = coef[i].cn == 0.f;          // the SDE solver (variance noise per step) keeps the three-launch boundary
@@ -266,7 +277,7 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
     // with the solver in its epilogue (vv_fused.hip).  The hidden rows alternate between two buffers: the boundary kernel of step i
     // reads the rows the layers of step i worked on while it writes the rows step i + 1 starts from.
     float* hb[2] = {hcur, hcur2};
-    VV_TRY(vv_head_init_fused(h, noise, Xs, Ms, hb[0], D, s));
+    if (!pre) VV_TRY(vv_head_init_fused(h, noise, Xs, Ms, hb[0], D, s));
     for (int i = 0; i < n_steps; ++i) {
       float* hc = hb[i & 1];
       for (int l = 0; l < h->layers; ++l) {
