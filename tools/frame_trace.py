@@ -85,6 +85,8 @@ def label_ops(frame, model="1.5b"):
             op, shp = [("llm.qkv", (2, qkv_n, H)), ("llm.attn_decode", (0, 0, 0)), ("llm.o", (2, H, cfg.q_dim)), ("llm.gate_up", (2, I, H)), ("llm.down", (2, H, I))][j]
         out.append((region, op, shp))
         idx += 1
+        if "adaln_" in n and region == "head_pre":      # the solver loop starts behind the adaLN kernel (head_init is part of head_pre_kernel since round 3)
+            region, idx = "head", 0
         if "conv_ctx_scatter" in n and gathers == 2:
             region, idx = "connect", 0
     return out
