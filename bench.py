@@ -447,9 +447,23 @@ def launch_ranks(n, argv, timeout=None):
     """Parent of a self-launched N-rank run (no torchrun): one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
     rank 0's stdout relayed to ours, every rank's stderr inherited.  The parent never touches the GPU (no exec from a process that
     has).  Returns the exit code: 0 only if every rank returned 0; the first failure ends the other ranks (exact PIDs)."""
+    import signal
     import subprocess
     port = int(os.environ.get("MASTER_PORT") or _free_port())
     procs = []
+
+    def reap(*_):            # the parent was told to stop (driver timeout, Ctrl-C): the ranks must not outlive it holding the GPUs
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except Exception:      # noqa: BLE001
+                p.kill()
+        raise SystemExit(143)
+    signal.signal(signal.SIGTERM, reap)
+    signal.signal(signal.SIGINT, reap)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_WORLD_SIZE=str(n))

@@ -491,18 +491,20 @@ class Engine:
         n_side = min(max_streams, len(wavs)) - 1
         side = [pool.pop() if pool else torch.cuda.Stream(self.device) for _ in range(n_side)]
         streams = [self.stream] + side
-        for st in side:
-            st.wait_stream(self.stream)                     # inputs were produced on / ordered into the engine stream
         outs = []
-        for i, w in enumerate(wavs):
-            st = streams[i % len(streams)]
-            o = self.acoustic_encode(w, stream=st)
-            if st is not self.stream:
-                o.record_stream(self.stream)
-            outs.append(o)
-        for st in side:
-            self.stream.wait_stream(st)
-            pool.append(st)
+        try:
+            for st in side:
+                st.wait_stream(self.stream)                 # inputs were produced on / ordered into the engine stream
+            for i, w in enumerate(wavs):
+                st = streams[i % len(streams)]
+                o = self.acoustic_encode(w, stream=st)
+                if st is not self.stream:
+                    o.record_stream(self.stream)
+                outs.append(o)
+        finally:                                            # streams go back to the pool whatever happened (they are never just dropped)
+            for st in side:
+                self.stream.wait_stream(st)
+                pool.append(st)
         return outs
 
     def connector(self, which: str, x: torch.Tensor) -> torch.Tensor:
