@@ -319,7 +319,7 @@ def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
                      "not the headline metric, which is one dialogue per GPU")
 
 
-def batched_leg(model, cfg, args, batch=4):
+def batched_leg(model, cfg, args, batch=4, row_batch=None):
     """Extra (NOT the headline value): ONE generate() call on a batch of `batch` dialogues of the headline shape - the reference's own
     batch dimension (modeling_vibevoice_inference.py:459-653).  The samples advance in lock step on one engine lane each (own HIP stream,
     KV cache and conv state, shared weights), one host loop."""
@@ -332,6 +332,8 @@ def batched_leg(model, cfg, args, batch=4):
               speech_noise=(torch.cat([w["speech_noise"][0] for w in wls]), torch.cat([w["speech_noise"][1] for w in wls])),
               generation_config={"do_sample": False}, show_progress_bar=False,
               max_length_times=max(2, -(-len(wls[0]["forced"]) // ids.shape[1]) + 1))
+    if row_batch is not None:
+        kw["row_batch"] = row_batch
     n, dt = 0, None
     for timed in (False, True):
         torch.cuda.synchronize()

@@ -35,7 +35,7 @@ enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
 /* vv_lin_args.flags: bf16 activation hand-off between two matrix-core GEMMs (x / out point at bf16 [m, ld] arrays, no
  * prologue on a bf16 x), and a hint that the weights are re-read soon (keep them cacheable instead of streaming them
  * non-temporally: the diffusion head's matrices are reused by every one of the N solver steps of a frame) */
-enum { VV_LIN_X_BF16 = 1, VV_LIN_OUT_BF16 = 2, VV_LIN_W_REUSED = 4 };
+enum { VV_LIN_X_BF16 = 1, VV_LIN_OUT_BF16 = 2, VV_LIN_W_REUSED = 4, VV_LIN_W_FRAG = 8 };
 
 const char* vv_last_error(void);
 int vv_abi_version(void);
@@ -174,6 +174,10 @@ typedef struct vv_llm_layer {
   const void* wup;
   const void* wdown; /* [hidden, inter] */
   vv_w8 q_qkv, q_o, q_gate, q_up, q_down;
+  /* optional fragment-major copies of the five matrices (NULL: none) for a row-batched decode step (5..8 rows = {positive, negative} x up to 4
+   * dialogues, vv_gemv_rows.hip): [N / 16][K / 32][4][16][8], i.e. element (16 g + n, 32 j + 8 c + e) of the row-major matrix at
+   * ((g * K/32 + j) * 64 + 16 c + n) * 8 + e - one matrix-core B fragment per 1 KB of contiguous memory.  N % 16 == 0, K % 32 == 0. */
+  const void* f_qkv; const void* f_o; const void* f_gate; const void* f_up; const void* f_down;
 } vv_llm_layer;
 
 typedef struct vv_llm {
@@ -199,6 +203,15 @@ int vv_llm_tail(const vv_llm* m, const float* h, int64_t ldh, int R, float* out,
                 float* logits_out, int* token_out, const int* forced_token, int* lens, int tok_start, int tok_diffusion, int* frame_counter,
                 vv_stream_t stream);
 
+/* One decode step for B dialogues batched into the row dimension: vv_llm_forward with R = 2 B rows (dialogue b = rows 2 b, 2 b + 1 of x, lens and
+ * of a KV cache with rows >= 2 B) streams the weights once for all of them; vv_llm_tail_batch then does for every dialogue what vv_llm_tail does
+ * for one: h = the un-normalised rows at the start of the LLM workspace, out[2 B, hidden], logits_out[B][8], token_out[B], forced_token[B] or NULL,
+ * lens[2 B], frame_counter[B]; active[B] (or NULL = all): a dialogue with active == 0 has finished - its rows are computed and dropped, its
+ * positions stay where they are. */
+int vv_llm_tail_batch(const vv_llm* m, const float* h, int64_t ldh, int B, float* out, int64_t ldo, const void* w_valid, int nv, const int* ids,
+                      float* logits_out, int* token_out, const int* forced_token, int* lens, int tok_start, int tok_diffusion, int* frame_counter,
+                      const int* active, vv_stream_t stream);
+
 typedef struct vv_head_layer {
   const float* norm_w;
   const void* wgate;  /* [ffn, D] */
@@ -206,6 +219,7 @@ typedef struct vv_head_layer {
   const void* wdown;  /* [D, ffn] */
   const void* adaln;  /* [3D, D]: shift | scale | gate */
   vv_w8 q_gate, q_up, q_down;
+  const void* f_gate; const void* f_up; const void* f_down;   /* optional fragment-major copies (see vv_llm_layer) */
 } vv_head_layer;
 
 typedef struct vv_head {
@@ -246,6 +260,13 @@ int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_cond, const 
                    const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, void* ws,
                    const float* sde_noise /* [n_steps, latent] per-step variance noise of the SDE solver (dpm_solver.py:993-998) or NULL */,
                    vv_stream_t stream);
+/* sample_speech_tokens for B utterances at once (B <= 4; the ODE solver on the fused boundary, bf16 weights): cond[2 B, cond_dim] = rows
+ * {positive, negative} of utterance b at 2 b, 2 b + 1; noise[b * ld_noise ..], latent_out[b * ld_latent ..].  Every head matrix is streamed once
+ * per solver step for all utterances.  ws: vv_head_ws_bytes_batch(h, n_steps, B) bytes. */
+size_t vv_head_ws_bytes_batch(const vv_head* h, int n_steps, int B);
+int vv_head_sample_batch(const vv_head* h, const float* cond, int64_t ld_cond, const float* noise, int64_t ld_noise, const float* temb,
+                         const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, int64_t ld_latent, int B, void* ws,
+                         vv_stream_t stream);
 /* VibeVoiceDiffusionHead.forward alone (parity tests): x[R, latent], temb_rows[R, D], cond[R, cond_dim] -> v[R, latent] */
 int vv_head_forward(const vv_head* h, const float* x, const float* temb_rows, const float* cond, int R, float* v,
                     void* ws, vv_stream_t stream);

@@ -306,7 +306,8 @@ def test_batch_of_four_lockstep_equals_singles_and_interleaves_streams(big):
         events.append([int(i) for i in idx])
         put0(chunks, idx)
     st.put = spy
-    out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise, audio_streamer=st)
+    out = m.generate(input_ids=ids, attention_mask=mask, tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise, audio_streamer=st,
+                     row_batch=False)          # the lanes: same kernels as a single run (the row-batched path has its own tests, test_hip_rowbatch.py)
     assert len(m._lanes) >= 4
     for b in range(4):
         one = m.generate(input_ids=prompts[b][None], tokenizer=tok, cfg_scale=2.0, forced_tokens=forced[b], noise=noise[b])

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.vv_abi_version() == 5
+    assert lib.vv_abi_version() == 6
 
 
 def test_integration_md_struct_mirrors_match_the_library():

@@ -8,7 +8,13 @@ lib = L.load()
 st = torch.cuda.Stream()
 
 
-def chain(m, n, k, dual, copies, pro=1, mod=False, epi=False, flags=0, N=120, tune=()):
+def frag_major(w):
+    """[N, K] bf16 -> the fragment-major copy [N / 16][K / 32][4][16][8] of vv_gemv_rows.hip (VV_LIN_W_FRAG)"""
+    n, k = w.shape
+    return w.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def chain(m, n, k, dual, copies, pro=1, mod=False, epi=False, flags=0, N=120, tune=(), frag=False):
     for key, val in tune:
         lib.vv_tune(key.encode(), val)
     with torch.cuda.stream(st):
@@ -16,6 +22,9 @@ def chain(m, n, k, dual, copies, pro=1, mod=False, epi=False, flags=0, N=120, tu
         bufs = [torch.randn(m, ld, device="cuda") * 0.5 for _ in range(2)]
         ws = [((torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16(), (torch.randn(n, k, device="cuda") / k ** 0.5).bfloat16() if dual else None)
               for _ in range(copies)]
+        if frag:
+            ws = [(frag_major(a_), frag_major(b_) if b_ is not None else None) for a_, b_ in ws]
+            flags |= L.LIN_W_FRAG
         nw = torch.ones(k, device="cuda"); sh = torch.zeros(m, k, device="cuda"); sc = torch.zeros(m, k, device="cuda")
         gate = torch.full((m, n), 0.5, device="cuda"); res = torch.zeros(m, ld, device="cuda")
         args = []
@@ -52,7 +61,7 @@ def chain(m, n, k, dual, copies, pro=1, mod=False, epi=False, flags=0, N=120, tu
         lib.vv_graph_destroy(ge)
     byts = n * k * 2 * (2 if dual else 1)
     floor = 3.2 + byts / 7.9e6
-    print(f"m={m} n={n:5d} k={k:5d} dual={int(dual)} copies={copies:2d} pro={pro} mod={int(mod)} epi={int(epi)} flags={flags} tune={tune}: {best:6.2f} us/kernel  "
+    print(f"m={m} n={n:5d} k={k:5d} dual={int(dual)} copies={copies:2d} pro={pro} mod={int(mod)} epi={int(epi)} flags={flags} frag={int(frag)} tune={tune}: {best:6.2f} us/kernel  "
           f"({byts / 1e6:5.1f} MB, {byts / best / 1e3:6.0f} GB/s; synthetic floor {floor:5.2f})", flush=True)
     for key, _ in tune:
         lib.vv_tune(key.encode(), 0 if key == "gemv_blocks" else {"gemv_dual_rw": 1, "gemv_small_rw": 2}.get(key, 0))

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libvv_hip.so")
 VV_F32, VV_BF16, VV_FP8 = 0, 1, 2
 PRO_NONE, PRO_RMSNORM, PRO_SILU = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_SWIGLU = 0, 1, 2
-LIN_X_BF16, LIN_OUT_BF16, LIN_W_REUSED = 1, 2, 4
+LIN_X_BF16, LIN_OUT_BF16, LIN_W_REUSED, LIN_W_FRAG = 1, 2, 4, 8
 VV_MAX_STAGES = 8
 
 vp = C.c_void_p
@@ -40,7 +40,8 @@ class KV(C.Structure):
 
 class LlmLayer(C.Structure):
     _fields_ = [("ln1", vp), ("ln2", vp), ("wqkv", vp), ("bqkv", vp), ("wo", vp), ("wgate", vp), ("wup", vp), ("wdown", vp),
-                ("q_qkv", W8), ("q_o", W8), ("q_gate", W8), ("q_up", W8), ("q_down", W8)]
+                ("q_qkv", W8), ("q_o", W8), ("q_gate", W8), ("q_up", W8), ("q_down", W8),
+                ("f_qkv", vp), ("f_o", vp), ("f_gate", vp), ("f_up", vp), ("f_down", vp)]
 
 
 class Llm(C.Structure):
@@ -50,7 +51,8 @@ class Llm(C.Structure):
 
 
 class HeadLayer(C.Structure):
-    _fields_ = [("norm_w", vp), ("wgate", vp), ("wup", vp), ("wdown", vp), ("adaln", vp), ("q_gate", W8), ("q_up", W8), ("q_down", W8)]
+    _fields_ = [("norm_w", vp), ("wgate", vp), ("wup", vp), ("wdown", vp), ("adaln", vp), ("q_gate", W8), ("q_up", W8), ("q_down", W8),
+                ("f_gate", vp), ("f_up", vp), ("f_down", vp)]
 
 
 class Head(C.Structure):
@@ -124,7 +126,10 @@ PROTOTYPES = {
     "vv_llm_ws_bytes": (C.c_size_t, [C.POINTER(Llm), C.c_int]),
     "vv_llm_forward": (C.c_int, [C.POINTER(Llm), C.POINTER(KV), vp, i64, C.c_int, vp, vp, vp, i64, vp, vp]),
     "vv_llm_tail": (C.c_int, [C.POINTER(Llm), vp, i64, C.c_int, vp, i64, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "vv_llm_tail_batch": (C.c_int, [C.POINTER(Llm), vp, i64, C.c_int, vp, i64, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "vv_head_ws_bytes": (C.c_size_t, [C.POINTER(Head), C.c_int]),
+    "vv_head_ws_bytes_batch": (C.c_size_t, [C.POINTER(Head), C.c_int, C.c_int]),
+    "vv_head_sample_batch": (C.c_int, [C.POINTER(Head), vp, i64, vp, i64, vp, C.POINTER(DpmCoef), C.c_int, C.c_float, vp, i64, C.c_int, vp, vp]),
     "vv_head_sample": (C.c_int, [C.POINTER(Head), vp, i64, vp, vp, C.POINTER(DpmCoef), C.c_int, C.c_float, vp, vp, vp, vp]),
     "vv_head_forward": (C.c_int, [C.POINTER(Head), vp, vp, vp, C.c_int, vp, vp, vp]),
     "vv_convnet_ws_bytes": (C.c_size_t, [C.POINTER(ConvNet), i64, C.c_int]),

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("vv_kernels.hip", "vv_gemv_stream.hip", "vv_mfma_gemm.hip", "vv_block1d.hip", "vv_convffn.hip",
+SRC = [os.path.join(HERE, "csrc", f) for f in ("vv_kernels.hip", "vv_gemv_stream.hip", "vv_gemv_rows.hip", "vv_mfma_gemm.hip", "vv_block1d.hip", "vv_convffn.hip",
                                                "vv_fused.hip", "vv_attn_decode.hip", "vv_attn_prefill.hip", "vv_model.hip")]
 HDR = [os.path.join(ROOT, "include", "vv_hip.h"), os.path.join(HERE, "csrc", "vv_common.h")]
 OUT = os.path.join(HERE, "libvv_hip.so")

@@ -21,6 +21,14 @@ int vv_set_error(int code, const char* fmt, ...);
   } while (0)
 
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_stream.hip: 1 = launched, 0 = not covered
+// vv_gemv_rows.hip: 5..8 activation rows on the matrix cores; 1 launched, 0 not covered, < 0 error.  part / tickets: split-K workspace
+// (vv_gemv_rows_part_floats / vv_gemv_rows_tickets give the sizes; tickets zero on entry, left zero) or null
+int vv_launch_gemv_rows(const vv_lin_args& a, float* part, size_t part_floats, int* tickets, size_t n_tickets, hipStream_t s);
+size_t vv_gemv_rows_part_floats(int n, int dual);
+size_t vv_gemv_rows_tickets(int n);
+int vv_gemv_rows_init();
+void vv_gemv_rows_set(int on, int blocks, int pers);            // tuning hooks (negative / zero: keep)
+int vv_linear_ws(const vv_lin_args* a, float* part, size_t part_floats, int* tickets, size_t n_tickets, vv_stream_t stream);   // vv_kernels.hip
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
 int vv_mfma_gemm_init();
 // vv_attn_decode.hip: bf16 KV cache, head_dim 128; part / tickets = split-key workspace ([R, heads, nsplit, 130] floats, [R, heads] zeroed ints) or null
@@ -37,6 +45,9 @@ int vv_head_init_fused(const vv_head* h, const float* noise, float* Xs, float* M
 bool vv_head_boundary_supported(const vv_head* h);
 int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
                            const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s);
+int vv_head_boundary_batch(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
+                           const vv_dpm_coef* k, float* Xs, float* Ms, int64_t state_stride, float* h_out, int64_t ldh_out, float* latent_out,
+                           int64_t latent_stride, int B, hipStream_t s);   // B dialogues per launch: rows 2 b, 2 b + 1; state / sample of b at b * stride
 int vv_fused_init();
 int vv_head_pre_fused(const vv_head* h, const float* cond2, int64_t ld_cond, const float* temb, int n_steps, void* c_bf16, const float* noise,
                       float* Xs, float* Ms, float* h0, int64_t ldh, hipStream_t s);   // cond_proj + silu(c0 + temb) rows (bf16) + solver-state init in one launch; 1 launched, 0 not covered

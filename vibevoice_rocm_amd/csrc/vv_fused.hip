@@ -61,10 +61,17 @@ struct BoundaryArgs {
   float* h_out; int64_t ldh_out;                    // [2, D] next step's hidden rows (both = P x'), a DIFFERENT buffer than h
   float* latent_out;       // [latent] x' (the last step's value is the sample)
   int D, latent;
+  // dialogues batched into one launch (blockIdx.y = b): hidden / modulation rows 2 b, 2 b + 1; solver state and sample of b at these strides
+  int64_t state_stride, latent_stride;
 };
 
 template <int KU>
-__global__ __launch_bounds__(256) void head_boundary_kernel(const BoundaryArgs a) {
+__global__ __launch_bounds__(256) void head_boundary_kernel(BoundaryArgs a) {
+  {
+    const int b = blockIdx.y;
+    a.h += 2 * b * a.ldh; a.shift += 2 * b * a.ld_mod; a.scale += 2 * b * a.ld_mod;
+    a.Xs += b * a.state_stride; a.Ms += b * a.state_stride; a.h_out += 2 * b * a.ldh_out; a.latent_out += b * a.latent_stride;
+  }
   __shared__ __attribute__((aligned(16))) float ys[KU * 512];
   __shared__ float red[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,11 +183,12 @@ __global__ __launch_bounds__(256) void head_boundary_kernel(const BoundaryArgs a
   }
 }
 
-template <int KU> void launch_boundary(const BoundaryArgs& a, hipStream_t s) {
+template <int KU> void launch_boundary(const BoundaryArgs& a, int B, hipStream_t s) {
   const int n = a.D + a.latent;
   int blocks = (n + 3) / 4;
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL((head_boundary_kernel<KU>), dim3(blocks), dim3(256), 0, s, a);
+  if (B > 1 && blocks > 256) blocks = 256;         // B dialogues share the chip
+  hipLaunchKernelGGL((head_boundary_kernel<KU>), dim3(blocks, B), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -240,7 +248,15 @@ __global__ __launch_bounds__(256) void llm_tail_kernel(const float* h, int64_t l
 template <typename WT>
 __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int64_t ldh, int R, int H, const float* norm_w, float eps, float* out, int64_t ldo,
                                                             const WT* w_valid, int nv, const int* ids, float* logits_out, int* token_out, const int* forced,
-                                                            int* lens, int tok_start, int tok_diff, int* frame_ctr) {
+                                                            int* lens, int tok_start, int tok_diff, int* frame_ctr, const int* active) {
+  {   // dialogues of a row-batched step: block b owns rows 2 b, 2 b + 1 and the b-th token / forced token / counters
+    const int b = blockIdx.x;
+    h += (int64_t)2 * b * ldh; out += (int64_t)2 * b * ldo; logits_out += 8 * b; token_out += b;
+    if (forced) forced += b;
+    if (lens) lens += 2 * b;
+    if (frame_ctr) frame_ctr += b;
+    if (active) active += b;
+  }
   constexpr int NC = 4, NV = 8;                    // column chunks (of 4) per thread per row, constrained ids
   __shared__ float red[4][2];
   __shared__ float lgp[4][NV];
@@ -269,6 +285,7 @@ __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int6
 #pragma unroll
   for (int i = 0; i < NV; ++i) idv[i] = ids[i < nv ? i : 0];
   const int fv = forced ? *forced : -1;
+  const int live = active ? *active : 1;
   const int l0 = lens ? lens[0] : 0, l1 = lens ? lens[1] : 0, fc = frame_ctr ? *frame_ctr : 0;
   float ss[2] = {0.f, 0.f};
 #pragma unroll
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(256) void llm_tail_fast_kernel(const float* h, int6
     }
     const int t = fv >= 0 ? fv : idv[best];
     *token_out = t;
-    if (lens) {
+    if (lens && live) {                              // a finished dialogue of the batch keeps its positions (its rows are computed and dropped)
       lens[0] = l0 + 1;
       if (tok_start < 0) { lens[1] = l1 + 1; if (t == tok_diff && frame_ctr) *frame_ctr = fc + 1; }   // refresh_negative=False: the negative row consumes every token
       else if (t == tok_start) lens[1] = 0;
@@ -769,18 +786,26 @@ bool vv_head_boundary_supported(const vv_head* h) {
 
 int vv_head_boundary_fused(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
                            const vv_dpm_coef* k, float* Xs, float* Ms, float* h_out, int64_t ldh_out, float* latent_out, hipStream_t s) {
+  return vv_head_boundary_batch(h, hrows, ldh, shift, scale, ld_mod, cfg, k, Xs, Ms, 0, h_out, ldh_out, latent_out, 0, 1, s);
+}
+
+// B dialogues in one launch: hidden rows [2 B] (dialogue b: rows 2 b, 2 b + 1), modulation rows likewise, solver state / sample of b at b * stride
+int vv_head_boundary_batch(const vv_head* h, const float* hrows, int64_t ldh, const float* shift, const float* scale, int64_t ld_mod, float cfg,
+                           const vv_dpm_coef* k, float* Xs, float* Ms, int64_t state_stride, float* h_out, int64_t ldh_out, float* latent_out,
+                           int64_t latent_stride, int B, hipStream_t s) {
   BoundaryArgs a;
+  a.state_stride = state_stride; a.latent_stride = latent_stride;
   a.G = h->fused_g; a.h = hrows; a.ldh = ldh; a.shift = shift; a.scale = scale; a.ld_mod = ld_mod; a.eps = h->eps; a.cfg = cfg; a.k = *k;
   a.Xs = Xs; a.Ms = Ms; a.h_out = h_out; a.ldh_out = ldh_out; a.latent_out = latent_out; a.D = h->D; a.latent = h->latent;
   switch ((h->D + 511) / 512) {
-    case 1: launch_boundary<1>(a, s); break;
-    case 2: launch_boundary<2>(a, s); break;
-    case 3: launch_boundary<3>(a, s); break;
-    case 4: launch_boundary<4>(a, s); break;
-    case 5: launch_boundary<5>(a, s); break;
-    case 6: launch_boundary<6>(a, s); break;
-    case 7: launch_boundary<7>(a, s); break;
-    case 8: launch_boundary<8>(a, s); break;
+    case 1: launch_boundary<1>(a, B, s); break;
+    case 2: launch_boundary<2>(a, B, s); break;
+    case 3: launch_boundary<3>(a, B, s); break;
+    case 4: launch_boundary<4>(a, B, s); break;
+    case 5: launch_boundary<5>(a, B, s); break;
+    case 6: launch_boundary<6>(a, B, s); break;
+    case 7: launch_boundary<7>(a, B, s); break;
+    case 8: launch_boundary<8>(a, B, s); break;
     default: return vv_set_error(VV_E_UNSUPPORTED, "vv_head_boundary_fused: D=%d", h->D);
   }
   VV_CHECK_LAUNCH("vv_head_boundary_fused");
@@ -799,10 +824,10 @@ extern "C" int vv_llm_tail(const vv_llm* m, const float* h, int64_t ldh, int R, 
       ((uintptr_t)w_valid % (m->wdt == VV_F32 ? 16 : 8)) == 0 && (m->wdt == VV_F32 || m->hidden % 4 == 0)) {
     if (m->wdt == VV_F32)
       hipLaunchKernelGGL((llm_tail_fast_kernel<float>), dim3(1), dim3(256), 0, s, h, ldh, R, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const float*)w_valid, nv,
-                         ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter);
+                         ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter, (const int*)nullptr);
     else
       hipLaunchKernelGGL((llm_tail_fast_kernel<bf16_t>), dim3(1), dim3(256), 0, s, h, ldh, R, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const bf16_t*)w_valid,
-                         nv, ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter);
+                         nv, ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter, (const int*)nullptr);
     VV_CHECK_LAUNCH("vv_llm_tail");
     return 0;
   }
@@ -813,6 +838,27 @@ extern "C" int vv_llm_tail(const vv_llm* m, const float* h, int64_t ldh, int R, 
     hipLaunchKernelGGL((llm_tail_kernel<bf16_t>), dim3(1), dim3(256), lds, s, h, ldh, R, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const bf16_t*)w_valid, nv, ids,
                        logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter);
   VV_CHECK_LAUNCH("vv_llm_tail");
+  return 0;
+}
+
+// The tail of a row-batched decode step (B dialogues, rows {positive, negative} x B): block b does what vv_llm_tail does for dialogue b.
+extern "C" int vv_llm_tail_batch(const vv_llm* m, const float* h, int64_t ldh, int B, float* out, int64_t ldo, const void* w_valid, int nv, const int* ids,
+                                 float* logits_out, int* token_out, const int* forced_token, int* lens, int tok_start, int tok_diffusion,
+                                 int* frame_counter, const int* active, vv_stream_t stream) {
+  if (!m || !h || !out || !w_valid || !ids || !logits_out || !token_out) return vv_set_error(VV_E_ARG, "vv_llm_tail_batch: null pointer");
+  if (B <= 0 || B > 4 || nv <= 0 || nv > 8) return vv_set_error(VV_E_ARG, "vv_llm_tail_batch: B=%d (1..4) nv=%d (<= 8)", B, nv);
+  auto a16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  if (!(m->hidden % 4 == 0 && m->hidden <= 4096 && a16(h) && ldh % 4 == 0 && a16(out) && ldo % 4 == 0 && a16(m->final_norm) &&
+        ((uintptr_t)w_valid % (m->wdt == VV_F32 ? 16 : 8)) == 0))
+    return vv_set_error(VV_E_UNSUPPORTED, "vv_llm_tail_batch: hidden=%d / alignment not covered", m->hidden);
+  hipStream_t s = (hipStream_t)stream;
+  if (m->wdt == VV_F32)
+    hipLaunchKernelGGL((llm_tail_fast_kernel<float>), dim3(B), dim3(256), 0, s, h, ldh, 2, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const float*)w_valid, nv,
+                       ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter, active);
+  else
+    hipLaunchKernelGGL((llm_tail_fast_kernel<bf16_t>), dim3(B), dim3(256), 0, s, h, ldh, 2, m->hidden, m->final_norm, m->rms_eps, out, ldo, (const bf16_t*)w_valid,
+                       nv, ids, logits_out, token_out, forced_token, lens, tok_start, tok_diffusion, frame_counter, active);
+  VV_CHECK_LAUNCH("vv_llm_tail_batch");
   return 0;
 }
 

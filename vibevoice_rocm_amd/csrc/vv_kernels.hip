@@ -29,15 +29,31 @@ int vv_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* vv_last_error(void) { return g_err; }
-extern "C" int vv_abi_version(void) { return 5; }   // 5: vv_kv.vt in 32-key tiles, vv_attn_decode maintains it, vv_advance_lens tok_start < 0; 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL); 4: vv_block.dw_last / hs, vv_block_mid
+extern "C" int vv_abi_version(void) { return 6; }   // 6: fragment-major weight copies (vv_llm_layer.f_*, vv_head_layer.f_*, VV_LIN_W_FRAG), vv_llm_tail_batch, vv_head_sample_batch; 5: vv_kv.vt in 32-key tiles, vv_attn_decode maintains it, vv_advance_lens tok_start < 0; 2: vv_w8 fp8 companions, vv_dpm_coef.cn + variance-noise arguments; 3: vv_head.fused_g, vv_llm_tail, vv_llm_forward(out = NULL); 4: vv_block.dw_last / hs, vv_block_mid
 int vv_mixer_init();
 extern "C" int vv_init(void) {
   VV_TRY(vv_mixer_init());
   VV_TRY(vv_mfma_gemm_init());
   VV_TRY(vv_block1d_init());
   VV_TRY(vv_convffn_init());
+  VV_TRY(vv_gemv_rows_init());
   return vv_fused_init();
 }
+// process-wide split-K scratch of the 5..8-row matrix-core GEMV for PUBLIC vv_linear calls (micro-benchmarks and tests only, switched on by
+// vv_tune("gemv_rows_scratch", 1): one stream at a time).  The composites hand vv_linear_ws their own workspace instead.
+static float* g_rows_part = nullptr;
+static int* g_rows_tk = nullptr;
+static const size_t G_ROWS_PART_FLOATS = (size_t)4 << 20, G_ROWS_TICKETS = 4096;
+static int rows_scratch(int on) {
+  if (on && !g_rows_part) {
+    if (hipMalloc(&g_rows_part, G_ROWS_PART_FLOATS * sizeof(float)) != hipSuccess || hipMalloc(&g_rows_tk, G_ROWS_TICKETS * sizeof(int)) != hipSuccess ||
+        hipMemset(g_rows_tk, 0, G_ROWS_TICKETS * sizeof(int)) != hipSuccess)
+      return vv_set_error(VV_E_HIP, "vv_tune: gemv_rows_scratch allocation failed");
+  }
+  if (!on && g_rows_part) { (void)hipFree(g_rows_part); (void)hipFree(g_rows_tk); g_rows_part = nullptr; g_rows_tk = nullptr; }
+  return 0;
+}
+void vv_gemv_rows_set_dbg(int d);
 void vv_gemv_stream_set_blocks(int b);
 void vv_gemv_stream_set_waves(int w);
 void vv_gemv_stream_set_opt(int o);
@@ -61,6 +77,11 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_long_ku")) { vv_gemv_stream_set_long(0, value); return 0; }
   if (key && !strcmp(key, "gemv_blocks")) { vv_gemv_stream_set_blocks(value); return 0; }
   if (key && !strcmp(key, "gemv_waves")) { vv_gemv_stream_set_waves(value); return 0; }
+  if (key && !strcmp(key, "gemv_rows")) { vv_gemv_rows_set(value, 0, -1); return 0; }
+  if (key && !strcmp(key, "gemv_rows_blocks")) { vv_gemv_rows_set(-1, value, -1); return 0; }
+  if (key && !strcmp(key, "gemv_rows_pers")) { vv_gemv_rows_set(-1, 0, value); return 0; }
+  if (key && !strcmp(key, "gemv_rows_scratch")) return rows_scratch(value);
+  if (key && !strcmp(key, "gemv_rows_dbg")) { vv_gemv_rows_set_dbg(value); return 0; }
   if (key && !strcmp(key, "gemv_opt")) { vv_gemv_stream_set_opt(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }
@@ -513,6 +534,10 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
   if (vv_launch_skinny(a, s)) return 0;                          // a few rows x K = 512..2560, plain epilogue: the resampling convs (vv_convffn.hip)
   if (a.m <= 8) {
+    if (a.m > 4 && g_rows_part) {                               // 5..8 rows on the matrix cores (process-wide scratch: see rows_scratch)
+      const int rc = vv_launch_gemv_rows(a, g_rows_part, G_ROWS_PART_FLOATS, g_rows_tk, G_ROWS_TICKETS, s);
+      if (rc) return rc < 0 ? rc : 0;
+    }
     if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
       // 5..8 rows not covered above: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
@@ -633,6 +658,16 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   if (prof) { (void)hipEventRecord(pr.e1, s); g_prof.push_back(pr); }
   VV_CHECK_LAUNCH("vv_linear");
   return 0;
+}
+
+// vv_linear for the composites of a row-batched step: 5..8 rows go to the matrix-core GEMV with the caller's split-K workspace
+int vv_linear_ws(const vv_lin_args* a, float* part, size_t part_floats, int* tickets, size_t n_tickets, vv_stream_t stream) {
+  if (a && a->wdt == VV_BF16 && a->m > 4 && a->m <= 8 && a->x && a->w && a->out) {
+    const int rc = vv_launch_gemv_rows(*a, part, part_floats, tickets, n_tickets, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    if (rc == 1) { VV_CHECK_LAUNCH("vv_linear(rows)"); return 0; }
+  }
+  return vv_linear(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -48,13 +48,27 @@ static inline void use_w8(vv_lin_args& a, const vv_w8& q, const vv_w8* q2 = null
 #define VV_ATT_MAX_SPLIT 16        // per-head kernel
 #define VV_ATT_PART_SPLITS 128     // capacity of the partials workspace: the grouped kernel spreads long contexts over up to 128 splits per (row, KV head)
 
+// split-K workspace of the row-batched decode step (vv_gemv_rows.hip): the widest non-dual matrix is the one that splits K
+static size_t rows_part_floats(const vv_llm* m) {
+  const int qkvd = (m->heads + 2 * m->kv_heads) * m->head_dim;
+  const int n = qkvd > m->hidden ? qkvd : m->hidden;
+  const size_t a = vv_gemv_rows_part_floats(n, 0), b = vv_gemv_rows_part_floats(m->inter, 1) / 8;     // the dual kernel splits K at most two ways
+  return a > b ? a : b;
+}
+static size_t rows_tickets(const vv_llm* m) {
+  const int qkvd = (m->heads + 2 * m->kv_heads) * m->head_dim;
+  const int n = qkvd > m->inter ? qkvd : m->inter;
+  return vv_gemv_rows_tickets(n > m->hidden ? n : m->hidden);
+}
+
 extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   if (!m || R <= 0) return 0;
   const size_t qkv = (size_t)(m->heads + 2 * m->kv_heads) * m->head_dim;
   const size_t widest = (size_t)(m->inter > m->hidden ? m->inter : m->hidden);
   return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter) +
          al((size_t)R * m->head_dim) + (R >= VV_PREFILL_ROWS ? al((size_t)R * widest / 2 + 64) : 0) +
-         al((size_t)VV_ATT_ROWS * m->heads * VV_ATT_PART_SPLITS * (m->head_dim + 2)) + al((size_t)VV_ATT_ROWS * m->heads);   // split-key decode attention
+         al((size_t)VV_ATT_ROWS * m->heads * VV_ATT_PART_SPLITS * (m->head_dim + 2)) + al((size_t)VV_ATT_ROWS * m->heads) +   // split-key decode attention
+         ((R > 4 && R <= 8) ? al(rows_part_floats(m)) + al(rows_tickets(m)) : 0);                                            // split-K partials of the 5..8-row GEMV
 }
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
@@ -89,6 +103,23 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_llm_forward: %s", hipGetErrorString(e));
   }
   void* xb2 = prefill ? (void*)act : nullptr;      // bf16 SwiGLU output [R, inter] lives in the (otherwise unused) fp32 act buffer
+  // 5..8 rows (dialogues batched into the row dimension): the matrix-core GEMV with its split-K workspace, fragment-major weights when the model has them
+  const bool rows8 = decode && R > 4 && R <= 8 && m->wdt == VV_BF16;
+  float* rpart = nullptr;
+  int* rtick = nullptr;
+  size_t rpart_n = 0, rtick_n = 0;
+  if (rows8) {
+    rpart_n = rows_part_floats(m); rtick_n = rows_tickets(m);
+    rpart = c.take(rpart_n);
+    rtick = reinterpret_cast<int*>(c.take(rtick_n));
+    hipError_t e = hipMemsetAsync(rtick, 0, rtick_n * sizeof(int), s);
+    if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_llm_forward: %s", hipGetErrorString(e));
+  }
+  auto lin = [&](vv_lin_args& a, const void* f1, const void* f2) -> int {
+    if (!rows8) return vv_linear(&a, stream);
+    if (f1 && (!a.w2 || f2)) { a.w = f1; if (a.w2) a.w2 = f2; a.flags |= VV_LIN_W_FRAG; }
+    return vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream);
+  };
   for (int l = 0; l < m->layers; ++l) {
     const vv_llm_layer& L = m->layer[l];
     vv_lin_args a;
@@ -99,9 +130,9 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     } else {
       a = lin_base(hin, ldh, R, L.wqkv, qkvd, H, m->wdt, qkv, qkvd);
       a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln1; a.eps = m->rms_eps; a.bias = L.bqkv;
-      use_w8(a, L.q_qkv);
+      if (!rows8) use_w8(a, L.q_qkv);
     }
-    VV_TRY(vv_linear(&a, stream));
+    VV_TRY(lin(a, L.f_qkv, nullptr));
     if (decode) {
       VV_TRY(vv_attn_decode_ws(qkv, qkvd, R, m->heads, kv, l, rope, lens, att, qd, att_part, att_tickets, att_split, VV_ATT_PART_SPLITS, stream));   // decode: RoPE + append fused
     } else {
@@ -114,10 +145,10 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       a.flags = VV_LIN_X_BF16;
     } else {
       a = lin_base(att, qd, R, L.wo, H, qd, m->wdt, h, H);
-      use_w8(a, L.q_o);
+      if (!rows8) use_w8(a, L.q_o);
     }
     a.res = hin; a.ldres = ldh;
-    VV_TRY(vv_linear(&a, stream));
+    VV_TRY(lin(a, L.f_o, nullptr));
     hin = h; ldh = H;
     if (prefill) {
       VV_TRY(vv_cast_rows_bf16(h, H, R, H, VV_PRO_RMSNORM, L.ln2, m->rms_eps, xb, H, stream));
@@ -128,20 +159,20 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
       a.pro = VV_PRO_RMSNORM; a.norm_w = L.ln2; a.eps = m->rms_eps;
     }
     a.w2 = L.wup; a.act = VV_ACT_SWIGLU;
-    if (!prefill) use_w8(a, L.q_gate, &L.q_up);
+    if (!prefill && !rows8) use_w8(a, L.q_gate, &L.q_up);
     if (prefill) {            // the SwiGLU output is handed to the down projection in bf16: no separate cast pass
       a.out = reinterpret_cast<float*>(xb2); a.ldo = m->inter; a.flags |= VV_LIN_OUT_BF16;
     }
-    VV_TRY(vv_linear(&a, stream));
+    VV_TRY(lin(a, L.f_gate, L.f_up));
     if (prefill) {
       a = lin_base((const float*)xb2, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
       a.flags = VV_LIN_X_BF16;
     } else {
       a = lin_base(act, m->inter, R, L.wdown, H, m->inter, m->wdt, h, H);
-      use_w8(a, L.q_down);
+      if (!rows8) use_w8(a, L.q_down);
     }
     a.res = h; a.ldres = H;
-    VV_TRY(vv_linear(&a, stream));
+    VV_TRY(lin(a, L.f_down, nullptr));
   }
   if (!out) return 0;       // the caller runs the final norm itself (vv_llm_tail: norm + logits + token + bookkeeping in one launch)
   return vv_rmsnorm_rows(h, H, m->final_norm, m->rms_eps, R, H, out, ldo, s);
@@ -310,6 +341,71 @@ extern "C" int vv_head_sample(const vv_head* h, const float* cond2, int64_t ld_c
     VV_TRY(head_body(h, nullptr, 0, 2, mod, modf, 2 * (int64_t)i, hcur, act, v, stream));
   }
   (void)s;
+  return 0;
+}
+
+// B utterances per call: rows [2 B] everywhere the single-utterance sampler has 2; conditioning rows laid out [step][2 B]
+extern "C" size_t vv_head_ws_bytes_batch(const vv_head* h, int n_steps, int B) {
+  if (!h || n_steps <= 0 || B <= 0 || B > 4) return 0;
+  const size_t R = (size_t)2 * B * n_steps, D = h->D;
+  return al(8 * D) /*c0*/ + al(R * D) /*c (bf16 rows fit)*/ + (size_t)h->layers * al(R * 3 * D) + al(R * 2 * D) + 2 * al(8 * D) /*hidden rows x 2*/ +
+         al(8 * (size_t)h->ffn) + 2 * al((size_t)B * (D + h->latent)) /*solver state X, M*/ +
+         al(vv_gemv_rows_part_floats(h->D, 0)) + al(vv_gemv_rows_tickets(h->ffn));
+}
+
+extern "C" int vv_head_sample_batch(const vv_head* h, const float* cond, int64_t ld_cond, const float* noise, int64_t ld_noise, const float* temb,
+                                    const vv_dpm_coef* coef, int n_steps, float cfg_scale, float* latent_out, int64_t ld_latent, int B, void* ws,
+                                    vv_stream_t stream) {
+  if (!h || !cond || !noise || !temb || !coef || !latent_out || !ws) return vv_set_error(VV_E_ARG, "vv_head_sample_batch: null pointer");
+  if (n_steps <= 0 || h->layers > 16 || B <= 0 || B > 4) return vv_set_error(VV_E_ARG, "vv_head_sample_batch: n_steps=%d layers=%d B=%d (1..4)", n_steps, h->layers, B);
+  for (int i = 0; i < n_steps; ++i)
+    if (coef[i].cn != 0.f) return vv_set_error(VV_E_UNSUPPORTED, "vv_head_sample_batch: the SDE solver is served per utterance (vv_head_sample)");
+  if (h->wdt != VV_BF16 || !vv_head_boundary_supported(h) || h->D % 32)
+    return vv_set_error(VV_E_UNSUPPORTED, "vv_head_sample_batch: needs bf16 weights and the fused solver boundary (vv_head.fused_g)");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = h->D, R2 = 2 * B;
+  const size_t R = (size_t)R2 * n_steps;
+  Carver cv(ws);
+  float* c0 = cv.take(8 * (size_t)D);
+  float* c = cv.take(R * D);
+  float* mod[16];
+  for (int l = 0; l < h->layers; ++l) mod[l] = cv.take(R * 3 * D);
+  float* modf = cv.take(R * 2 * D);
+  float* hb[2] = {cv.take(8 * (size_t)D), cv.take(8 * (size_t)D)};
+  float* act = cv.take(8 * (size_t)h->ffn);
+  const int64_t sst = D + h->latent;
+  float* Xs = cv.take((size_t)B * sst);
+  float* Ms = cv.take((size_t)B * sst);
+  const size_t rpart_n = vv_gemv_rows_part_floats(h->D, 0), rtick_n = vv_gemv_rows_tickets(h->ffn);
+  float* rpart = cv.take(rpart_n);
+  int* rtick = reinterpret_cast<int*>(cv.take(rtick_n));
+  if (hipMemsetAsync(rtick, 0, rtick_n * sizeof(int), s) != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_sample_batch: memset");
+  // step-invariant work: cond_proj on all rows, silu(cond_proj(cond) + t_emb(t_i)) as bf16 rows [step][2 B], every adaLN modulation
+  vv_lin_args a = lin_base(cond, ld_cond, R2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
+  VV_TRY(vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream));
+  VV_TRY(vv_add_rows_silu_bf16(c0, D, temb, D, c, (int)R, R2, D, stream));
+  VV_TRY(head_modulations(h, c, (int)R, mod, modf, true, true, stream));
+  for (int b = 0; b < B; ++b)
+    VV_TRY(vv_head_init_fused(h, noise + (size_t)b * ld_noise, Xs + (size_t)b * sst, Ms + (size_t)b * sst, hb[0] + (size_t)2 * b * D, D, s));
+  for (int i = 0; i < n_steps; ++i) {
+    float* hc = hb[i & 1];
+    for (int l = 0; l < h->layers; ++l) {
+      const vv_head_layer& L = h->layer[l];
+      const float* ml = mod[l] + (size_t)R2 * i * 3 * D;
+      a = lin_base(hc, D, R2, L.wgate, h->ffn, D, h->wdt, act, h->ffn);
+      a.pro = VV_PRO_RMSNORM; a.norm_w = L.norm_w; a.eps = h->eps;
+      a.mod_shift = ml; a.mod_scale = ml + D; a.ld_mod = 3 * D;
+      a.w2 = L.wup; a.act = VV_ACT_SWIGLU; a.flags = VV_LIN_W_REUSED;
+      if (L.f_gate && L.f_up) { a.w = L.f_gate; a.w2 = L.f_up; a.flags |= VV_LIN_W_FRAG; }
+      VV_TRY(vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream));
+      a = lin_base(act, h->ffn, R2, L.wdown, D, h->ffn, h->wdt, hc, D);
+      a.gate = ml + 2 * D; a.gate_ld = 3 * D; a.res = hc; a.ldres = D; a.flags = VV_LIN_W_REUSED;
+      if (L.f_down) { a.w = L.f_down; a.flags |= VV_LIN_W_FRAG; }
+      VV_TRY(vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream));
+    }
+    const float* mf = modf + (size_t)R2 * i * 2 * D;
+    VV_TRY(vv_head_boundary_batch(h, hc, D, mf, mf + D, 2 * D, cfg_scale, &coef[i], Xs, Ms, sst, hb[(i + 1) & 1], D, latent_out, ld_latent, B, s));
+  }
   return 0;
 }
 

@@ -138,6 +138,9 @@ class VibeVoiceForConditionalGenerationInference:
         # launch a frame's diffusion tail right behind the LLM step while the host still waits for the token (rolled back when the
         # token is not speech_diffusion); results are identical either way (tests/test_hip_parity.py)
         self.speculative_frames = True
+        # batches of 3..4 dialogues: one weight pass per frame for all of them (rowbatch.py) instead of one per dialogue (lanes)
+        self.row_batch = os.environ.get("VV_ROW_BATCH", "1") != "0"
+        self._rowbatch = {}
         # weight_quant="fp8": weight-only e4m3 companions for the per-frame weight-streaming GEMVs
         self.weight_quant = weight_quant
         self.engine = Engine(config, state_dict, device=device, dtype=torch_dtype, use_graphs=use_graphs, weight_quant=weight_quant)
@@ -283,7 +286,11 @@ class VibeVoiceForConditionalGenerationInference:
                 # with refresh_negative=False the reference's batched loop couples the samples (a non-diffusing sample's negative step is
                 # dropped only in steps where some OTHER sample diffuses, :588-622): served per sample here would not reproduce that
                 raise NotImplementedError("refresh_negative=False is built for batch size 1 only")
-            return self._generate_lockstep(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
+            rb = kwargs.get("row_batch", self.row_batch)
+            fn = self._generate_lockstep
+            if rb and 2 < B <= 4 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
+                fn = self._generate_rowbatch      # dialogues batched into the row dimension of the LLM / diffusion-head weight passes (rowbatch.py)
+            return fn(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
                                            forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
                                            audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev)
         seqs, audios, reach = [], [], []
@@ -514,6 +521,158 @@ class VibeVoiceForConditionalGenerationInference:
             pool.shutdown()
         for e in lanes[:B]:
             e.stream.synchronize()
+        if audio_streamer is not None:
+            audio_streamer.end()
+        pad_id = getattr(tokenizer, "pad_id", None)
+        if pad_id is None:
+            pad_id = special["eos"]
+        rows = []
+        for b in range(B):
+            rows.append(torch.cat([input_ids[b][~keep[b]], torch.tensor(seq[b], dtype=torch.long)]))
+        mx = max(r.shape[0] for r in rows)
+        seq_t = torch.full((B, mx), int(pad_id), dtype=torch.long)
+        for b, r in enumerate(rows):
+            seq_t[b, : r.shape[0]] = r
+        audios = [(torch.cat(c)[None] if c else None) for c in chunks]
+        return VibeVoiceGenerationOutput(sequences=seq_t.to(in_dev), speech_outputs=audios if return_speech else None,
+                                         reach_max_step_sample=torch.tensor(reach, dtype=torch.bool))
+
+    def _generate_rowbatch(self, input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
+                           forced_tokens, noise, sde_noise, audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev):
+        """The lock-step loop of `_generate_lockstep` with the B dialogues batched into the ROW dimension of the weight-heavy half of a frame
+        (rowbatch.RowBatch: one Qwen2 decode step with 2 B rows, one diffusion sampling with 2 B rows; the conv tokenizers stay per dialogue on
+        their lanes' streams).  Token handling, the draws' order, speculation and rollback are the same; results agree with the lanes to the
+        rounding of the matrix-core GEMV (activations as bf16 hi + lo, ~2e-6 relative per product)."""
+        from .rowbatch import RowBatch
+        cfg = self.config
+        B, Lp = input_ids.shape
+        ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
+        valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
+        lanes = [self._lane(b) for b in range(B)]
+        rb = self._rowbatch.get(B)
+        if rb is None:
+            rb = self._rowbatch[B] = RowBatch(lanes)
+        keep = attention_mask.bool()
+        L0 = keep.sum(-1).tolist()
+        max_length = cfg.max_pos if max_new_tokens is None else Lp + int(max_new_tokens)            # :370-371 (padded length, as the reference)
+        max_steps = min(max_length - Lp, int(max_length_times * Lp))                                # :420
+        max_step_per_sample = [min(max_length - l, int(max_length_times * l)) for l in L0]          # :421
+        per_list = forced_tokens is not None and len(forced_tokens) > 0 and isinstance(forced_tokens[0], (list, tuple))
+        ftok = [(forced_tokens[b] if per_list else forced_tokens) for b in range(B)]
+        nz = [(noise[b] if (noise is not None and noise.dim() == 3) else noise) for b in range(B)]
+        rb.begin(max(L0) + max(max_steps, 1) + 8, valid, cfg_scale)
+        x0s, off = [], 0
+        with torch.cuda.stream(rb.stream):
+            for b in range(B):
+                x0 = self.engine.embed_ids(input_ids[b][keep[b]])
+                if speech_input_mask is not None and conn_all is not None:
+                    sp_b = speech_input_mask[b][keep[b]].bool()
+                    n_b = int(sp_b.sum())
+                    if n_b:
+                        x0[sp_b.to(self.device)] = conn_all[off: off + n_b]                         # :221-224
+                        off += n_b
+                x0s.append(x0)
+        seq = [input_ids[b][keep[b]].tolist() for b in range(B)]
+        chunks = [[] for _ in range(B)]
+        frame = [0] * B
+        finished = [False] * B
+        reach = [False] * B
+        prev_tok = [None] * B
+        pending = []
+        ours = [False] * max(B, getattr(audio_streamer, "batch_size", B) if audio_streamer is not None else B)
+        speculate = self.speculative_frames and self._use_graphs
+
+        def deliver():
+            if audio_streamer is None or not pending:
+                pending.clear()
+                return
+            idx = [b for b, _ in pending]
+            audio_streamer.put(torch.stack([lanes[b].take_chunk(k)[None] for b, k in pending]), torch.tensor(idx))   # one put per step, all samples (:644-653)
+            pending.clear()
+
+        def finish(b):
+            finished[b] = True
+            rb.set_active(b, False)
+            if audio_streamer is not None:
+                deliver()
+                ours[b] = True
+                audio_streamer.end(torch.tensor([b]))
+
+        for step in range(max_steps):
+            if stop_check_fn is not None and stop_check_fn():                                       # :432-438
+                if verbose:
+                    print(f"Generation stopped externally at step {step + 1}")
+                deliver()
+                if audio_streamer is not None:
+                    audio_streamer.end()
+                break
+            if audio_streamer is not None and hasattr(audio_streamer, "finished_flags") and \
+                    any(f and not ours[i] for i, f in enumerate(audio_streamer.finished_flags)):
+                break                                                                               # :441-445, see _generate_lockstep
+            if all(finished):
+                break
+            if Lp + step >= max_length:                                                             # :452-457
+                for b in range(B):
+                    reach[b] = reach[b] or not finished[b]
+                break
+            live = [b for b in range(B) if not finished[b]]
+            forced = {b: (ftok[b][step] if (ftok[b] is not None and step < len(ftok[b])) else None) for b in live}
+            toks = {}
+            speculated = set()
+            if step == 0:
+                for b in live:
+                    rb.prefill(b, x0s[b], chunk=getattr(self, "_prefill_chunk", 1024))
+                for b in live:
+                    toks[b] = rb.first_token(b, forced[b])
+                    if toks[b] == SD:
+                        rb.prefill(b, self.engine.embed_ids(torch.tensor([ST])), neg=True)
+            else:
+                # one graph A for every dialogue; in the steady state of the batch (every live dialogue diffusing, noise injected) the
+                # diffusion sampling and the conv tails go out speculatively behind it
+                spec = speculate and all(prev_tok[b] == SD and nz[b] is not None and frame[b] < len(nz[b]) for b in live)
+                rb.decode_begin(ST, SD, forced)
+                if spec:
+                    rb.speech(live, {b: nz[b][frame[b]] for b in live})
+                    speculated = set(live)
+                deliver()                  # the previous step's chunks: their copies completed long before this step's tokens
+                tk = rb.decode_end()
+                toks = {b: tk[b] for b in live}
+            diffusing = []
+            for b in live:
+                tok = toks[b]
+                if b in speculated and tok != SD:
+                    rb.rollback(b)
+                prev_tok[b] = tok
+                seq[b].append(tok)
+                if tok == EOS:                                                                      # :517-526
+                    if verbose:
+                        print(f"Samples [{b}] reached EOS token at step {step + 1}.", flush=True)
+                    finish(b)
+                    continue
+                if step >= max_step_per_sample[b]:                                                  # :528-537
+                    reach[b] = True
+                    finish(b)
+                    continue
+                if tok == SE:                                                                       # :540-544
+                    rb.reset_speech(b)
+                if tok == SD:
+                    diffusing.append(b)
+                else:
+                    rb.embed(b)                                                                     # :567
+            todo = [b for b in diffusing if b not in speculated]
+            if todo:
+                need = [b for b in todo if nz[b] is None or frame[b] >= len(nz[b])]
+                drawn = torch.randn(2 * len(need), cfg.latent)[: len(need)] if need else None     # the reference's draw for n diffusing samples (:699)
+                rows = {b: (drawn[need.index(b)] if b in need else nz[b][frame[b]]) for b in todo}
+                rb.speech(todo, rows)
+            for b in diffusing:                                                                     # :571-670
+                with torch.cuda.stream(lanes[b].stream):
+                    chunks[b].append(lanes[b].wav.clone())
+                if audio_streamer is not None:
+                    pending.append((b, lanes[b].stage_chunk()))
+                frame[b] += 1
+        deliver()
+        rb.synchronize()
         if audio_streamer is not None:
             audio_streamer.end()
         pad_id = getattr(tokenizer, "pad_id", None)

@@ -1,0 +1,318 @@
+"""Row-batched decode for the dialogues of ONE generate() call (reference: the batched loop of modeling_vibevoice_inference.py:430-673).
+
+`Engine` lanes run B dialogues as B independent launch chains that each stream every LLM and diffusion-head weight once per frame.  Here the
+B dialogues (2 <= B <= 4) share ONE chain for the two weight-heavy parts of a frame:
+
+  graph A   Qwen2 decode step with R = 2 B rows (dialogue b = rows {2 b: positive, 2 b + 1: negative} of x, lens and one KV cache with 2 B
+            rows): every weight matrix is read once for all dialogues (5..8 rows: the matrix-core GEMV of csrc/vv_gemv_rows.hip on
+            fragment-major weight copies), then vv_llm_tail_batch = final norm, constrained logits, argmax / forced token and position
+            bookkeeping per dialogue;
+  graph H   vv_head_sample_batch: the CFG diffusion sampler for all B utterances, 2 B rows through every head matrix per solver step.
+
+The conv tokenizers (acoustic decode, semantic encode) and the connectors stay per dialogue - each has its own streaming state - and run as
+B concurrent hipGraphs on the lanes' streams between H and the next A (events fork / join them), exactly the launch sequences the lanes use.
+The host loop, token state machine, speculation and rollback are those of the lock-step loop (modeling.py)."""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .engine import Engine
+
+_UID = itertools.count(1)
+
+
+class RowBatch:
+    def __init__(self, lanes: List[Engine]):
+        self.lanes = lanes
+        self.B = B = len(lanes)
+        if not 2 <= B <= 4:
+            raise L.VVError("row batching serves 2..4 dialogues per call")
+        eng = self.main = lanes[0]
+        self.lib, self.cfg, self.device, self.stream = eng.lib, eng.cfg, eng.device, eng.stream
+        if eng.dtype != torch.bfloat16 or eng.kv_dtype != torch.bfloat16 or eng.w.quant is not None:
+            raise L.VVError("row batching needs bf16 weights and a bf16 KV cache")
+        self.uid = next(_UID)
+        cfg, H = self.cfg, self.cfg.hidden
+        f32 = dict(dtype=torch.float32, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        with torch.cuda.stream(self.stream):
+            eng.w.ensure_frag()
+            self.x = torch.zeros(2 * B, H, **f32)
+            self.hidden = torch.zeros(2 * B, H, **f32)
+            self.lens = torch.zeros(2 * B, **i32)
+            self.frame_ctr = torch.zeros(B, **i32)
+            self.token_dev = torch.zeros(B, **i32)
+            self.forced_dev = torch.full((B,), -1, **i32)
+            self.active_dev = torch.ones(B, **i32)
+            self.logits = torch.zeros(B, 8, **f32)
+            self.noise_dev = torch.zeros(B, cfg.latent, **f32)
+            self.latent = torch.zeros(B, cfg.latent, **f32)
+            self._llm_ws = torch.empty(self.lib.vv_llm_ws_bytes(C.byref(eng.w.llm), 2 * B), dtype=torch.uint8, device=self.device)
+        self._pf_ws = None
+        self._pf_rows = 0
+        self.token_host = torch.zeros(B, dtype=torch.int32).pin_memory()
+        self.forced_host = torch.full((B,), -1, dtype=torch.int32).pin_memory()
+        self.active_host = torch.ones(B, dtype=torch.int32).pin_memory()
+        self.noise_host = torch.zeros(2, B, cfg.latent, dtype=torch.float32).pin_memory()
+        self._noise_k = 0
+        self._forced_val = [-1] * B
+        self._active_val = [1] * B
+        self._tok_event = torch.cuda.Event()
+        self._head_event = torch.cuda.Event()
+        self._lane_event = [torch.cuda.Event() for _ in range(B)]
+        self._lane_dirty = [False] * B      # lane b has work in flight that the next graph A must wait for
+        self.kv = None
+        self._kv_t = None
+        self._graphs: Dict[tuple, int] = {}
+        self._head_ws = None
+        self._head_steps = 0
+        self.valid_ids: List[int] = []
+        self._w_valid = None
+        self._ids_dev = None
+
+    # -----------------------------------------------------------------------------------------------------------------
+    @property
+    def sp(self) -> int:
+        return self.stream.cuda_stream
+
+    def _ck(self, rc, what):
+        L.check(rc, what)
+
+    def _drop_graphs(self):
+        for g in self._graphs.values():
+            self.lib.vv_graph_destroy(g)
+        self._graphs = {}
+
+    def close(self):
+        self._drop_graphs()
+
+    def _run(self, name: str, fn, *args):
+        if not self.main.use_graphs:
+            fn(*args)
+            return
+        key = (name,) + tuple(args)
+        g = self._graphs.get(key)
+        if g is None:
+            self.stream.synchronize()
+            self._ck(self.lib.vv_graph_begin(self.sp), "graph begin")
+            try:
+                fn(*args)
+            finally:
+                ge = C.c_void_p()
+                rc = self.lib.vv_graph_end(self.sp, C.byref(ge))
+            self._ck(rc, "graph end")
+            g = ge.value
+            self._graphs[key] = g
+        self._ck(self.lib.vv_graph_launch(g, self.sp), "graph launch")
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def begin(self, s_max: int, valid_ids: List[int], cfg_scale: float):
+        """Fresh batch: one KV cache with 2 B rows sized for s_max tokens, every lane's conv state zeroed."""
+        cfg, eng, B = self.cfg, self.main, self.B
+        s_max = (int(s_max) + 63) // 64 * 64
+        self.cfg_scale = float(cfg_scale)
+        for e in self.lanes[1:]:
+            e.sync_in()
+            e.stream.wait_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            if self.kv is None or self.kv.s_max < s_max:
+                shape = (cfg.layers, 2 * B, cfg.kv_heads, s_max, cfg.head_dim)
+                self._kv_t = (torch.zeros(shape, dtype=torch.bfloat16, device=self.device), torch.zeros(shape, dtype=torch.bfloat16, device=self.device))
+                kv = L.KV()
+                kv.k, kv.v = self._kv_t[0].data_ptr(), self._kv_t[1].data_ptr()
+                if cfg.head_dim == 128:
+                    self._kv_vt = torch.empty((cfg.layers, 2 * B, cfg.kv_heads, s_max // 32, cfg.head_dim, 32), dtype=torch.bfloat16, device=self.device)
+                    kv.vt = self._kv_vt.data_ptr()
+                kv.kvdt = L.VV_BF16
+                kv.layers, kv.rows, kv.kv_heads, kv.s_max, kv.head_dim = cfg.layers, 2 * B, cfg.kv_heads, s_max, cfg.head_dim
+                self.kv = kv
+                self._drop_graphs()
+            ids = sorted(set(int(i) for i in valid_ids))
+            if ids != self.valid_ids:
+                if len(ids) > 8:
+                    raise L.VVError("row batching serves at most 8 constrained vocabulary ids")
+                self.valid_ids = ids
+                arr = (C.c_int * len(ids))(*ids)
+                self._w_valid = torch.empty(len(ids), cfg.hidden, dtype=torch.bfloat16, device=self.device)
+                self._ck(self.lib.vv_gather_rows(eng.w.lm_head.data_ptr(), eng.w.wdt, cfg.hidden, arr, len(ids), self._w_valid.data_ptr(), self.sp), "vv_gather_rows")
+                self._ids_dev = torch.tensor(ids, dtype=torch.int32, device=self.device)
+                self._drop_graphs()
+            if self._head_steps != eng.n_steps:
+                self._head_ws = torch.empty(self.lib.vv_head_ws_bytes_batch(C.byref(eng.w.head), eng.n_steps, B), dtype=torch.uint8, device=self.device)
+                self._head_steps = eng.n_steps
+                self._drop_graphs()
+            self.lens.zero_()
+            self.frame_ctr.zero_()
+            self.forced_dev.fill_(-1)
+            self.active_dev.fill_(1)
+            self._forced_val = [-1] * B
+            self._active_val = [1] * B
+        for e in self.lanes:
+            with torch.cuda.stream(e.stream):
+                e.reset_speech_caches()
+        self._lane_dirty = [False] * B
+
+    def prefill(self, b: int, embeds: torch.Tensor, neg: bool = False, chunk: int = 1024):
+        """Prompt prefill of dialogue b on cache row 2 b (neg: 2 b + 1), on the main stream; hidden[row] = last hidden state."""
+        row = 2 * b + (1 if neg else 0)
+        L0 = embeds.shape[0]
+        n_chunks = max(1, -(-L0 // max(1, chunk)))
+        size = -(-L0 // n_chunks)
+        size = min(chunk, (size + 31) // 32 * 32) if n_chunks > 1 else L0
+        with torch.cuda.stream(self.stream):
+            if max(size, 1) > self._pf_rows:
+                self._pf_rows = max(size, 64)
+                self._pf_ws = torch.empty(self.lib.vv_llm_ws_bytes(C.byref(self.main.w.llm), self._pf_rows), dtype=torch.uint8, device=self.device)
+            for c0 in range(0, L0, size):
+                c1 = min(L0, c0 + size)
+                n = c1 - c0
+                lens = torch.arange(c0, c1, dtype=torch.int32, device=self.device)
+                rows = torch.full((n,), row, dtype=torch.int32, device=self.device)
+                out = torch.empty(n, self.cfg.hidden, dtype=torch.float32, device=self.device)
+                xe = embeds[c0:c1].contiguous()
+                self._ck(self.lib.vv_llm_forward(C.byref(self.main.w.llm), C.byref(self.kv), xe.data_ptr(), xe.stride(0), n, lens.data_ptr(), rows.data_ptr(),
+                                                 out.data_ptr(), out.stride(0), self._pf_ws.data_ptr(), self.sp), "vv_llm_forward")
+            self.hidden[row].copy_(out[-1])
+            self.lens[row] = L0
+
+    def first_token(self, b: int, forced: Optional[int]) -> int:
+        """Token selection right after the prefill of dialogue b (hidden[2 b] holds its last prompt state)."""
+        nv = len(self.valid_ids)
+        with torch.cuda.stream(self.stream):
+            self._set_forced({b: forced})
+            a = L.LinArgs()
+            a.x, a.ldx, a.m = self.hidden[2 * b].data_ptr(), self.cfg.hidden, 1
+            a.w, a.n, a.k, a.wdt = self._w_valid.data_ptr(), nv, self.cfg.hidden, L.VV_BF16
+            a.out, a.ldo = self.logits[b].data_ptr(), nv
+            self._ck(self.lib.vv_linear(C.byref(a), self.sp), "lm_head")
+            self._ck(self.lib.vv_argmax_ids(self.logits[b].data_ptr(), nv, self._ids_dev.data_ptr(), self.token_dev[b:].data_ptr(),
+                                            self.forced_dev[b:].data_ptr(), self.sp), "vv_argmax_ids")
+            self.token_host.copy_(self.token_dev, non_blocking=True)
+        self.stream.synchronize()
+        return int(self.token_host[b])
+
+    # -----------------------------------------------------------------------------------------------------------------
+    def _set_forced(self, forced: Dict[int, Optional[int]]):
+        """Device-side forced tokens (-1: none), uploaded only when one changes (see Engine._set_forced)."""
+        changed = False
+        for b, f in forced.items():
+            v = -1 if f is None else int(f)
+            if v != self._forced_val[b]:
+                self._forced_val[b] = v
+                self.forced_host[b] = v
+                changed = True
+        if changed:
+            self.forced_dev.copy_(self.forced_host, non_blocking=True)
+
+    def set_active(self, b: int, on: bool):
+        """A finished dialogue stays in the row batch (its rows are computed and dropped) but no longer advances its positions."""
+        v = 1 if on else 0
+        if v != self._active_val[b]:
+            self._active_val[b] = v
+            self.active_host[b] = v
+            with torch.cuda.stream(self.stream):
+                self.active_dev.copy_(self.active_host, non_blocking=True)
+
+    def _seq_A(self, tok_start, tok_diff):
+        eng, B, H = self.main, self.B, self.cfg.hidden
+        nv = len(self.valid_ids)
+        self._ck(self.lib.vv_llm_forward(C.byref(eng.w.llm), C.byref(self.kv), self.x.data_ptr(), H, 2 * B, self.lens.data_ptr(), None, None, 0,
+                                         self._llm_ws.data_ptr(), self.sp), "vv_llm_forward")
+        self._ck(self.lib.vv_llm_tail_batch(C.byref(eng.w.llm), self._llm_ws.data_ptr(), H, B, self.hidden.data_ptr(), H, self._w_valid.data_ptr(), nv,
+                                            self._ids_dev.data_ptr(), self.logits.data_ptr(), self.token_dev.data_ptr(), self.forced_dev.data_ptr(),
+                                            self.lens.data_ptr(), tok_start, tok_diff, self.frame_ctr.data_ptr(), self.active_dev.data_ptr(), self.sp),
+                 "vv_llm_tail_batch")
+
+    def _seq_H(self, cfg_scale):
+        eng, cfg = self.main, self.cfg
+        self._ck(self.lib.vv_head_sample_batch(C.byref(eng.w.head), self.hidden.data_ptr(), cfg.hidden, self.noise_dev.data_ptr(), cfg.latent,
+                                               eng.temb.data_ptr(), eng._coefs, eng.n_steps, cfg_scale, self.latent.data_ptr(), cfg.latent, self.B,
+                                               self._head_ws.data_ptr(), self.sp), "vv_head_sample_batch")
+
+    def _seq_conv(self, b, uid):
+        """acoustic decode -> semantic encode -> connectors of dialogue b on ITS stream, into rows 2 b, 2 b + 1 of the next step's input"""
+        e, cfg = self.lanes[b], self.cfg
+        lib, w = self.lib, e.w
+        blob = w.state_blob()
+        self._ck(lib.vv_copy_rows(blob.data_ptr(), blob.numel(), e._state_snap.data_ptr(), blob.numel(), 1, blob.numel(), e.sp), "snapshot")
+        lat = self.latent[b].data_ptr()
+        self._ck(lib.vv_decoder_forward(C.byref(w.dec), lat, 1, 1.0 / w.speech_scale, -w.speech_bias, e.wav.data_ptr(), e._dec_ws.data_ptr(), e.sp),
+                 "vv_decoder_forward")
+        self._ck(lib.vv_encoder_forward(C.byref(w.sem), e.wav.data_ptr(), cfg.hop, e.sem.data_ptr(), e._sem_ws.data_ptr(), e.sp), "vv_encoder_forward")
+        self._ck(lib.vv_connector_pair(C.byref(w.ac_conn), C.byref(w.sem_conn), lat, e.sem.data_ptr(), self.x[2 * b].data_ptr(), cfg.hidden, 2,
+                                       e.conn_ws.data_ptr(), e.sp), "connectors")
+
+    def _seq_embed(self, b, uid):
+        e, cfg = self.lanes[b], self.cfg
+        self._ck(self.lib.vv_embed_row(e.w.embed.data_ptr(), e.w.wdt, cfg.hidden, self.token_dev[b:].data_ptr(), self.x[2 * b].data_ptr(), e.sp), "embed")
+        self._ck(self.lib.vv_copy_rows(self.x[2 * b].data_ptr(), 0, self.x[2 * b + 1].data_ptr(), cfg.hidden, 1, cfg.hidden, e.sp), "copy")
+
+    def _join_lanes(self):
+        """the next graph A reads every lane's rows of x"""
+        for b in range(1, self.B):
+            if self._lane_dirty[b]:
+                self.stream.wait_event(self._lane_event[b])
+                self._lane_dirty[b] = False
+
+    def _lane_done(self, b):
+        if b:
+            self._lane_event[b].record(self.lanes[b].stream)
+            self._lane_dirty[b] = True
+
+    def decode_begin(self, tok_start: int, tok_diff: int, forced: Dict[int, Optional[int]]):
+        """graph A for all dialogues + the asynchronous token read-back; `decode_end` returns the tokens."""
+        with torch.cuda.stream(self.stream):
+            self._join_lanes()
+            self._set_forced(forced)
+            self._run("A", self._seq_A, int(tok_start), int(tok_diff))
+            self.token_host.copy_(self.token_dev, non_blocking=True)
+            self._tok_event.record(self.stream)
+
+    def decode_end(self) -> List[int]:
+        self._tok_event.synchronize()
+        return [int(t) for t in self.token_host]
+
+    def speech(self, which: List[int], noise: Dict[int, torch.Tensor]):
+        """Diffusion sampling for the whole batch (graph H), then the conv tail of the dialogues in `which`, each on its own stream."""
+        cfg = self.cfg
+        with torch.cuda.stream(self.stream):
+            self._noise_k ^= 1
+            nh = self.noise_host[self._noise_k]
+            for b in which:
+                nh[b].copy_(noise[b].reshape(-1)[: cfg.latent])
+            self.noise_dev.copy_(nh, non_blocking=True)
+            self._run("H", self._seq_H, float(self.cfg_scale))
+            self._head_event.record(self.stream)
+        for b in which:
+            e = self.lanes[b]
+            with torch.cuda.stream(e.stream):
+                if b:
+                    e.stream.wait_event(self._head_event)
+                e._run("RBconv", self._seq_conv, b, self.uid)
+                self._lane_done(b)
+
+    def embed(self, b: int):
+        """next input of dialogue b = embed_tokens[its token], on its stream (after a rollback of that stream, if any)"""
+        e = self.lanes[b]
+        with torch.cuda.stream(e.stream):
+            if b:
+                e.stream.wait_event(self._tok_event)
+            e._run("RBembed", self._seq_embed, b, self.uid)
+            self._lane_done(b)
+
+    def rollback(self, b: int):
+        self.lanes[b].rollback_speech_state()
+
+    def reset_speech(self, b: int):
+        e = self.lanes[b]
+        with torch.cuda.stream(e.stream):
+            e.reset_speech_caches()
+
+    def synchronize(self):
+        for e in self.lanes:
+            e.stream.synchronize()

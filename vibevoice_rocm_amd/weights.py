@@ -13,7 +13,7 @@ Matrix weights are stored in `wdtype` (fp32 for graded parity, bf16 for the benc
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -175,6 +175,49 @@ class DeviceWeights:
         w.state_tensors = {k: [w._state_arena[(t.data_ptr() - old0) // f32: (t.data_ptr() - old0) // f32 + t.numel()].view_as(t) for t in v]
                            for k, v in self.state_tensors.items()}
         return w
+
+    @staticmethod
+    def frag_major(w: torch.Tensor) -> Optional[torch.Tensor]:
+        """[N, K] bf16 -> the fragment-major copy [N / 16][K / 32][4][16][8] (include/vv_hip.h, vv_llm_layer.f_*): element (16 g + n, 32 j + 8 c + e)
+        at ((g * K/32 + j) * 64 + 16 c + n) * 8 + e, one matrix-core B fragment per KB of contiguous memory."""
+        n, k = w.shape
+        if n % 16 or k % 32 or w.dtype != torch.bfloat16:
+            return None
+        return w.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+    def ensure_frag(self) -> None:
+        """Fragment-major copies of the LLM's and the diffusion head's per-frame matrices for the row-batched decode step (rowbatch.py): built
+        once, on first use, next to the row-major matrices (which the prefill GEMMs and the 1..4-row GEMVs keep using); +2.9 GB at 1.5B."""
+        if getattr(self, "_frag_done", False) or self.wdtype != torch.bfloat16:
+            return
+        by_ptr = {t.data_ptr(): t for t in self._keep if isinstance(t, torch.Tensor)}
+
+        def frag_of(p, n, k):
+            t = by_ptr.get(int(p)) if p else None
+            if t is None or tuple(t.shape) != (n, k):
+                return None
+            f = self.frag_major(t)
+            if f is None:
+                return None
+            f = self._aligned(f)
+            self._keep.append(f)
+            return f.data_ptr()
+
+        cfg = self.cfg
+        qkvd = (cfg.heads + 2 * cfg.kv_heads) * cfg.head_dim
+        for l in range(cfg.layers):
+            lay = self.llm.layer[l]
+            lay.f_qkv = frag_of(lay.wqkv, qkvd, cfg.hidden)
+            lay.f_o = frag_of(lay.wo, cfg.hidden, cfg.heads * cfg.head_dim)
+            lay.f_gate = frag_of(lay.wgate, cfg.inter, cfg.hidden)
+            lay.f_up = frag_of(lay.wup, cfg.inter, cfg.hidden)
+            lay.f_down = frag_of(lay.wdown, cfg.hidden, cfg.inter)
+        for l in range(cfg.head_layers):
+            lay = self.head.layer[l]
+            lay.f_gate = frag_of(lay.wgate, cfg.head_ffn, cfg.head_hidden)
+            lay.f_up = frag_of(lay.wup, cfg.head_ffn, cfg.head_hidden)
+            lay.f_down = frag_of(lay.wdown, cfg.head_hidden, cfg.head_ffn)
+        self._frag_done = True
 
     def state_blob(self) -> torch.Tensor:
         """All streaming state of the speech path as one flat fp32 tensor."""
