@@ -321,8 +321,9 @@ def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
 
 def batched_leg(model, cfg, args, batch=4, row_batch=None):
     """Extra (NOT the headline value): ONE generate() call on a batch of `batch` dialogues of the headline shape - the reference's own
-    batch dimension (modeling_vibevoice_inference.py:459-653).  The samples advance in lock step on one engine lane each (own HIP stream,
-    KV cache and conv state, shared weights), one host loop."""
+    batch dimension (modeling_vibevoice_inference.py:459-653).  The samples advance in lock step under one host loop: 3-4 dialogues batched
+    into the row dimension of the LLM / diffusion-head weight passes (rowbatch.py), otherwise (or row_batch=False) on one engine lane each
+    (own HIP stream, KV cache and conv state, shared weights)."""
     wls = [build_workload(cfg, args.frames, args.voice_frames, seed=201 + i) for i in range(batch)]
     ids = torch.cat([w["input_ids"] for w in wls])
     kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=wls[0]["tok"], cfg_scale=args.cfg_scale,
@@ -335,16 +336,20 @@ def batched_leg(model, cfg, args, batch=4, row_batch=None):
     if row_batch is not None:
         kw["row_batch"] = row_batch
     n, dt = 0, None
-    for timed in (False, True):
-        torch.cuda.synchronize()
+    for timed in (False, False, True):     # two warm-up calls: the first builds lanes / graphs, the second still grows the allocator's per-stream pools
+        torch.cuda.synchronize()           # (the first call's outputs are alive while it runs); a serving process is past both
         t0 = time.perf_counter()
         out = model.generate(**kw)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         n = sum(o.shape[-1] for o in out.speech_outputs)
     assert n == batch * args.frames * cfg.hop, (n, batch, args.frames)
-    return dict(batch=batch, value=round(n / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3),
-                note="one generate() call on a batch of dialogues of the headline shape, samples in lock step on one engine lane each; "
+    rowb = (model.row_batch if row_batch is None else row_batch) and 2 < batch <= 4
+    return dict(batch=batch, value=round(n / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3), row_batched=bool(rowb),
+                note="one generate() call on a batch of dialogues of the headline shape, in lock step; " +
+                     ("the dialogues are batched into the row dimension of the LLM and diffusion-head weight passes (one pass per frame for all of them, "
+                      "vibevoice_rocm_amd/rowbatch.py), conv tokenizers per dialogue; lanes_value = the same call with one engine lane per dialogue; "
+                      if rowb else "one engine lane per dialogue; ") +
                      "aggregate audio seconds per wall second, not the headline metric (one dialogue per GPU)")
 
 
@@ -755,6 +760,11 @@ def main():
         try:
             result["batched_generate"] = batched_leg(model, cfg, args, args.batched)
             log(f"batched x{args.batched}: {result['batched_generate']['value']} audio-sec/s aggregate")
+            if model.row_batch and 2 < args.batched <= 4:
+                # the same call with the dialogues on one engine lane each (one LLM / head weight pass per dialogue and frame), for comparison
+                lanes = batched_leg(model, cfg, args, args.batched, row_batch=False)
+                result["batched_generate"]["lanes_value"] = lanes["value"]
+                log(f"batched x{args.batched} on lanes: {lanes['value']} audio-sec/s aggregate")
         except Exception as e:      # noqa: BLE001
             result["batched_generate"] = {"error": repr(e)}
             log(f"batched leg failed: {e!r}")

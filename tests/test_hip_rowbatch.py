@@ -107,7 +107,18 @@ def test_rows_gemv_vs_torch(lib, shape, frag, m_rows):
             y = y * gate.double() + res.double()
         err = rel_rms(out.double().cpu().numpy(), y.cpu().numpy())
         assert err < 2e-5, f"rows GEMV m={m} n={n} k={k} dual={dual} frag={frag}: rel RMS {err:.3e}"
+        if epi:
+            # residual in place (res == out), as the composites call it: long K then adds every K slice to `out` with fp32 atomics
+            for atomic in (1, 0):
+                lib.vv_tune(b"gemv_rows_atomic", atomic)
+                out2 = res.clone()
+                a.res, a.out = out2.data_ptr(), out2.data_ptr()
+                L.check(lib.vv_linear(C.byref(a), torch.cuda.current_stream().cuda_stream), "vv_linear")
+                torch.cuda.synchronize()
+                err = rel_rms(out2.double().cpu().numpy(), y.cpu().numpy())
+                assert err < 2e-5, f"rows GEMV in place (atomic={atomic}) m={m} n={n} k={k} frag={frag}: rel RMS {err:.3e}"
     finally:
+        lib.vv_tune(b"gemv_rows_atomic", 1)
         lib.vv_tune(b"gemv_rows_scratch", 0)
 
 

@@ -48,6 +48,9 @@ __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); 
 __device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 struct RowsAux {
+  int atomic;        // ksplit > 1 with a linear epilogue whose residual already sits in `out` (res == out): every K slice adds gate * (partial [+ bias])
+                     // to out with fp32 atomics - no partial tiles, no ticket, nothing to wait for (the summation ORDER of the slices then varies from
+                     // run to run: results reproduce to fp32 rounding, ~1e-7, not bit for bit; vv_tune("gemv_rows_atomic", 0) keeps the ticket)
   int dbg;           // timing experiments (wrong results): 2 = no ticket merge, 4 = no activation loads
   float* part;       // [n_groups][ksplit][PST] partial tiles (ksplit > 1)
   int* tickets;      // [n_groups], zero on entry, left zero
@@ -263,6 +266,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_rows_kernel(const vv_lin_args a,
       }
     }
     float rs = 1.0f;
+    if (!PERS && ksplit > 1 && x.atomic) {
+      if (tid < 128) {
+        const int gn = g * 16 + en;
+        if (em < mr && gn < N) {
+          float v = s;
+          if (a.bias && ks == 0) v += eo.b;
+          if (a.gate) v *= eo.g;
+          atomicAdd(a.out + (int64_t)em * a.ldo + gn, v);
+        }
+      }
+      return;
+    }
     if (!PERS && ksplit > 1 && !(x.dbg & 2)) {
       // partial tile out (write-through), ticket, the last block of the row group folds
       float* pp = x.part + ((int64_t)g * ksplit + ks) * PST;
@@ -330,6 +345,7 @@ int g_rows_on = 1;          // tuning hook "gemv_rows": 0 = never take this path
 int g_rows_blocks = 448;    // row groups x K slices aimed for before the K split stops growing
 int g_rows_pers = 256;      // persistent blocks of the whole-row kernels (one 8-wave block per CU)
 int g_rows_dbg = 0;
+int g_rows_atomic = 1;      // tuning hook "gemv_rows_atomic": 0 = always fold K slices through the ticket (deterministic summation order)
 
 template <bool DUAL, int NW, int KS, bool PERS>
 int launch_cfg(const vv_lin_args& a, RowsAux x, int n_groups, hipStream_t s) {
@@ -344,6 +360,7 @@ int launch_cfg(const vv_lin_args& a, RowsAux x, int n_groups, hipStream_t s) {
 }  // namespace
 
 void vv_gemv_rows_set_dbg(int d) { g_rows_dbg = d; }
+void vv_gemv_rows_set_atomic(int on) { g_rows_atomic = on; }
 void vv_gemv_rows_set(int on, int blocks, int pers) {
   if (on >= 0) g_rows_on = on;
   if (blocks > 0) g_rows_blocks = blocks;
@@ -380,7 +397,7 @@ int vv_launch_gemv_rows(const vv_lin_args& a, float* part, size_t part_floats, i
   const bool dual = a.w2 != nullptr;
   const int steps = a.k / 32, n_groups = (a.n + 15) / 16;
   RowsAux x;
-  x.part = part; x.tickets = tickets; x.dbg = g_rows_dbg; x.n_groups = n_groups;
+  x.part = part; x.tickets = tickets; x.dbg = g_rows_dbg; x.n_groups = n_groups; x.atomic = 0;
   // whole rows per block when K <= 2048 (8 waves x <= 8 steps): no cross-block reduction at all
   if (steps <= 64) {
     x.ksplit = 1;
@@ -414,7 +431,8 @@ int vv_launch_gemv_rows(const vv_lin_args& a, float* part, size_t part_floats, i
   if (!ksplit) return 0;
   while (ksplit > 1 && (ksplit - 1) * NW * spw >= steps) --ksplit;     // drop K slices that would start past the end
   const size_t pst = dual ? 264 : 136;
-  if (!part || !tickets || (size_t)n_groups * ksplit * pst > part_floats || (size_t)n_groups > n_tickets) return 0;
+  x.atomic = g_rows_atomic && !dual && a.pro == VV_PRO_NONE && a.act == VV_ACT_NONE && a.res && a.res == a.out && a.ldres == a.ldo;
+  if (!x.atomic && (!part || !tickets || (size_t)n_groups * ksplit * pst > part_floats || (size_t)n_groups > n_tickets)) return 0;
   x.ksplit = ksplit; x.spw = spw;
   if (dual) {
     if (spw <= 4) return launch_cfg<true, 8, 4, false>(a, x, n_groups, s);

@@ -54,6 +54,7 @@ static int rows_scratch(int on) {
   return 0;
 }
 void vv_gemv_rows_set_dbg(int d);
+void vv_gemv_rows_set_atomic(int on);
 void vv_gemv_stream_set_blocks(int b);
 void vv_gemv_stream_set_waves(int w);
 void vv_gemv_stream_set_opt(int o);
@@ -82,6 +83,7 @@ extern "C" int vv_tune(const char* key, int value) {   // developer tuning hooks
   if (key && !strcmp(key, "gemv_rows_pers")) { vv_gemv_rows_set(-1, 0, value); return 0; }
   if (key && !strcmp(key, "gemv_rows_scratch")) return rows_scratch(value);
   if (key && !strcmp(key, "gemv_rows_dbg")) { vv_gemv_rows_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "gemv_rows_atomic")) { vv_gemv_rows_set_atomic(value); return 0; }
   if (key && !strcmp(key, "gemv_opt")) { vv_gemv_stream_set_opt(value); return 0; }
   if (key && !strcmp(key, "gemv_dual_rw")) { vv_gemv_stream_set_dual_rw(value); return 0; }
   if (key && !strcmp(key, "gemv_small_rw")) { vv_gemv_stream_set_small_rw(value); return 0; }

@@ -115,6 +115,10 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     hipError_t e = hipMemsetAsync(rtick, 0, rtick_n * sizeof(int), s);
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_llm_forward: %s", hipGetErrorString(e));
   }
+  if (rows8) {      // the residual stream lives in h from the start: the split-K projections then accumulate into it in place (vv_gemv_rows.hip)
+    VV_TRY(vv_copy_rows(x, ldx, h, H, R, H, stream));
+    hin = h; ldh = H;
+  }
   auto lin = [&](vv_lin_args& a, const void* f1, const void* f2) -> int {
     if (!rows8) return vv_linear(&a, stream);
     if (f1 && (!a.w2 || f2)) { a.w = f1; if (a.w2) a.w2 = f2; a.flags |= VV_LIN_W_FRAG; }
