@@ -14,7 +14,7 @@ sd = synth_state_dict_torch(cfg, 2024, device="cuda:0", dtype=torch.bfloat16)
 m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
 m.set_ddpm_inference_steps(20)
 args = types.SimpleNamespace(frames=frames, voice_frames=203, cfg_scale=2.0)
-for batch in (4, 3):
+for batch in [int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('4', '3'))]:
     for rb in (False, True, False, True):
         r = bench.batched_leg(m, cfg, args, batch, row_batch=rb)
         print(f"batch {batch} row_batch={rb}: {r['value']} audio-sec/s ({r['seconds']} s)", flush=True)

@@ -343,7 +343,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_rows_kernel(const vv_lin_args a,
 
 int g_rows_on = 1;          // tuning hook "gemv_rows": 0 = never take this path
 int g_rows_blocks = 448;    // row groups x K slices aimed for before the K split stops growing
-int g_rows_pers = 256;      // persistent blocks of the whole-row kernels (one 8-wave block per CU)
+int g_rows_pers = 192;      // persistent blocks of the whole-row SwiGLU kernels: each block's activation prologue is 150 KB of L2 reads, so FEWER blocks
+                            // than CUs win (head: 11.05 us at 144 blocks, 11.65 at 256, 15.2 at 288 one-shot blocks; LLM: 15.7 at 187, 16.9 at 256)
 int g_rows_dbg = 0;
 int g_rows_atomic = 1;      // tuning hook "gemv_rows_atomic": 0 = always fold K slices through the ticket (deterministic summation order)
 
@@ -351,7 +352,10 @@ template <bool DUAL, int NW, int KS, bool PERS>
 int launch_cfg(const vv_lin_args& a, RowsAux x, int n_groups, hipStream_t s) {
   const size_t lds = (size_t)NW * KS * 64 * 16;        // the LDS limit of every instantiation is raised in vv_gemv_rows_init (not capturable)
   int gx = n_groups;
-  if (PERS && gx > g_rows_pers) gx = g_rows_pers;
+  if (PERS && gx > g_rows_pers) {                       // the same number of row groups for every block
+    const int per = (n_groups + g_rows_pers - 1) / g_rows_pers;
+    gx = (n_groups + per - 1) / per;
+  }
   x.n_groups = n_groups;
   hipLaunchKernelGGL((gemv_rows_kernel<DUAL, NW, KS, PERS>), dim3(gx, x.ksplit), dim3(NW * 64), lds, s, a, x);
   return 1;

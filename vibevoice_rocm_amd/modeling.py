@@ -288,7 +288,7 @@ class VibeVoiceForConditionalGenerationInference:
                 raise NotImplementedError("refresh_negative=False is built for batch size 1 only")
             rb = kwargs.get("row_batch", self.row_batch)
             fn = self._generate_lockstep
-            if rb and 2 < B <= 4 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
+            if rb and int(os.environ.get("VV_ROW_BATCH_MIN", "3")) <= B <= 4 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
                 fn = self._generate_rowbatch      # dialogues batched into the row dimension of the LLM / diffusion-head weight passes (rowbatch.py)
             return fn(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
                                            forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
