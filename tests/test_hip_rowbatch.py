@@ -249,3 +249,34 @@ def test_generate_row_batch_vs_lanes(big):
     for b in range(3):
         err = rel_rms(out3.speech_outputs[b].float().cpu().numpy(), outs[False].speech_outputs[b].float().cpu().numpy())
         assert err < 1e-2, f"batch of 3, dialogue {b}: waveform rel RMS {err:.3e}"
+
+
+def test_generate_row_batch_7b_shapes_vs_lanes():
+    """VibeVoice-7B shapes (hidden 3584, 28 / 4 heads, head D = 3584): K = 3584 / 18944 take other forms of the GEMV (K split over two blocks
+    with the SwiGLU epilogue in the ticket merge, the ticket with the RMSNorm scalar factored out, 13-way split of the down projection; the
+    head's modulated SwiGLU GEMV falls back to the streaming kernels) - the row-batched call must still agree with the lanes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    from vibevoice_rocm_amd.synth import synth_state_dict_torch
+    cfg = VVConfig.preset("7b")
+    sd = synth_state_dict_torch(cfg, 777, device="cuda:0", dtype=torch.bfloat16)
+    m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
+    m.set_ddpm_inference_steps(10)
+    tok = _Tok(cfg.vocab)
+    D, E, S, EOS = tok.speech_diffusion_id, tok.speech_end_id, tok.speech_start_id, tok.eos_token_id
+    g = torch.Generator().manual_seed(41)
+    ids = torch.stack([torch.cat([torch.randint(0, 1000, (23,), generator=g), torch.tensor([S])]) for _ in range(3)])
+    forced = [[D] * 3 + [E, EOS], [D] * 2 + [E, EOS], [D] * 3 + [E, EOS]]
+    noise = torch.randn(3, 4, cfg.latent, generator=g)
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise)
+    lanes = m.generate(row_batch=False, **kw)
+    rows = m.generate(row_batch=True, **kw)
+    assert 3 in m._rowbatch and rows.sequences.tolist() == lanes.sequences.tolist()
+    for b in range(3):
+        err = rel_rms(rows.speech_outputs[b].float().cpu().numpy(), lanes.speech_outputs[b].float().cpu().numpy(),
+                      what=f"generate() on 3 dialogues at 7B shapes bf16, row-batched vs lanes, waveform of dialogue {b}")
+        assert err < 2e-2, f"7B shapes, dialogue {b}: waveform rel RMS {err:.3e}"
+    del m
+    torch.cuda.empty_cache()

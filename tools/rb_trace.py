@@ -19,7 +19,7 @@ kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=wls[0]["
           noise=torch.stack([w["noise"] for w in wls]), speech_tensors=torch.cat([w["speech_tensors"] for w in wls]).cuda(),
           speech_masks=torch.cat([w["speech_masks"] for w in wls]), speech_input_mask=torch.cat([w["speech_input_mask"] for w in wls]),
           speech_noise=(torch.cat([w["speech_noise"][0] for w in wls]), torch.cat([w["speech_noise"][1] for w in wls])),
-          generation_config={"do_sample": False}, show_progress_bar=False, max_length_times=4, row_batch=True)
+          generation_config={"do_sample": False}, show_progress_bar=False, max_length_times=2, row_batch=True)
 m.generate(**kw)
 rb = m._rowbatch[4]
 lib = rb.lib

@@ -28,7 +28,8 @@ size_t vv_gemv_rows_part_floats(int n, int dual);
 size_t vv_gemv_rows_tickets(int n);
 int vv_gemv_rows_init();
 void vv_gemv_rows_set(int on, int blocks, int pers);            // tuning hooks (negative / zero: keep)
-int vv_linear_ws(const vv_lin_args* a, float* part, size_t part_floats, int* tickets, size_t n_tickets, vv_stream_t stream);   // vv_kernels.hip
+int vv_linear_ws(const vv_lin_args* a, const void* f1, const void* f2, float* part, size_t part_floats, int* tickets, size_t n_tickets,
+                 vv_stream_t stream);   // vv_kernels.hip: f1 / f2 = fragment-major copies of a->w / a->w2 or null
 int vv_launch_mfma_gemm(const vv_lin_args& a, hipStream_t s);     // vv_mfma_gemm.hip: 1 launched, 0 not covered, <0 error
 int vv_mfma_gemm_init();
 // vv_attn_decode.hip: bf16 KV cache, head_dim 128; part / tickets = split-key workspace ([R, heads, nsplit, 130] floats, [R, heads] zeroed ints) or null

@@ -662,10 +662,13 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   return 0;
 }
 
-// vv_linear for the composites of a row-batched step: 5..8 rows go to the matrix-core GEMV with the caller's split-K workspace
-int vv_linear_ws(const vv_lin_args* a, float* part, size_t part_floats, int* tickets, size_t n_tickets, vv_stream_t stream) {
+// vv_linear for the composites of a row-batched step: 5..8 rows go to the matrix-core GEMV with the caller's split-K workspace, on the
+// fragment-major copies f1 / f2 of w / w2 when the model has them; shapes that kernel does not cover take vv_linear on the row-major matrices
+int vv_linear_ws(const vv_lin_args* a, const void* f1, const void* f2, float* part, size_t part_floats, int* tickets, size_t n_tickets, vv_stream_t stream) {
   if (a && a->wdt == VV_BF16 && a->m > 4 && a->m <= 8 && a->x && a->w && a->out) {
-    const int rc = vv_launch_gemv_rows(*a, part, part_floats, tickets, n_tickets, (hipStream_t)stream);
+    vv_lin_args b = *a;
+    if (f1 && (!b.w2 || f2)) { b.w = f1; if (b.w2) b.w2 = f2; b.flags |= VV_LIN_W_FRAG; }
+    const int rc = vv_launch_gemv_rows(b, part, part_floats, tickets, n_tickets, (hipStream_t)stream);
     if (rc < 0) return rc;
     if (rc == 1) { VV_CHECK_LAUNCH("vv_linear(rows)"); return 0; }
   }

@@ -121,8 +121,7 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
   }
   auto lin = [&](vv_lin_args& a, const void* f1, const void* f2) -> int {
     if (!rows8) return vv_linear(&a, stream);
-    if (f1 && (!a.w2 || f2)) { a.w = f1; if (a.w2) a.w2 = f2; a.flags |= VV_LIN_W_FRAG; }
-    return vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream);
+    return vv_linear_ws(&a, f1, f2, rpart, rpart_n, rtick, rtick_n, stream);
   };
   for (int l = 0; l < m->layers; ++l) {
     const vv_llm_layer& L = m->layer[l];
@@ -386,7 +385,7 @@ extern "C" int vv_head_sample_batch(const vv_head* h, const float* cond, int64_t
   if (hipMemsetAsync(rtick, 0, rtick_n * sizeof(int), s) != hipSuccess) return vv_set_error(VV_E_HIP, "vv_head_sample_batch: memset");
   // step-invariant work: cond_proj on all rows, silu(cond_proj(cond) + t_emb(t_i)) as bf16 rows [step][2 B], every adaLN modulation
   vv_lin_args a = lin_base(cond, ld_cond, R2, h->cond_proj, D, h->cond_dim, h->wdt, c0, D);
-  VV_TRY(vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream));
+  VV_TRY(vv_linear_ws(&a, nullptr, nullptr, rpart, rpart_n, rtick, rtick_n, stream));
   VV_TRY(vv_add_rows_silu_bf16(c0, D, temb, D, c, (int)R, R2, D, stream));
   VV_TRY(head_modulations(h, c, (int)R, mod, modf, true, true, stream));
   for (int b = 0; b < B; ++b)
@@ -400,12 +399,10 @@ extern "C" int vv_head_sample_batch(const vv_head* h, const float* cond, int64_t
       a.pro = VV_PRO_RMSNORM; a.norm_w = L.norm_w; a.eps = h->eps;
       a.mod_shift = ml; a.mod_scale = ml + D; a.ld_mod = 3 * D;
       a.w2 = L.wup; a.act = VV_ACT_SWIGLU; a.flags = VV_LIN_W_REUSED;
-      if (L.f_gate && L.f_up) { a.w = L.f_gate; a.w2 = L.f_up; a.flags |= VV_LIN_W_FRAG; }
-      VV_TRY(vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream));
+      VV_TRY(vv_linear_ws(&a, L.f_gate, L.f_up, rpart, rpart_n, rtick, rtick_n, stream));
       a = lin_base(act, h->ffn, R2, L.wdown, D, h->ffn, h->wdt, hc, D);
       a.gate = ml + 2 * D; a.gate_ld = 3 * D; a.res = hc; a.ldres = D; a.flags = VV_LIN_W_REUSED;
-      if (L.f_down) { a.w = L.f_down; a.flags |= VV_LIN_W_FRAG; }
-      VV_TRY(vv_linear_ws(&a, rpart, rpart_n, rtick, rtick_n, stream));
+      VV_TRY(vv_linear_ws(&a, L.f_down, nullptr, rpart, rpart_n, rtick, rtick_n, stream));
     }
     const float* mf = modf + (size_t)R2 * i * 2 * D;
     VV_TRY(vv_head_boundary_batch(h, hc, D, mf, mf + D, 2 * D, cfg_scale, &coef[i], Xs, Ms, sst, hb[(i + 1) & 1], D, latent_out, ld_latent, B, s));
