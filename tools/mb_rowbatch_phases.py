@@ -14,6 +14,9 @@ sd = synth_state_dict_torch(cfg, 2024, device="cuda:0", dtype=torch.bfloat16)
 m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
 m.set_ddpm_inference_steps(20)
 args = types.SimpleNamespace(frames=40, voice_frames=203, cfg_scale=2.0)
+import os
+if os.environ.get("VV_GEMV_OPT"):
+    m.engine.lib.vv_tune(b"gemv_opt", int(os.environ["VV_GEMV_OPT"]))
 bench.batched_leg(m, cfg, args, B, row_batch=True)
 rb = m._rowbatch[B]
 lib = rb.lib
@@ -51,6 +54,17 @@ def all_conv():
 
 
 print(f"conv tails, {B} dialogues on {B} streams: {timeit(all_conv):.3f} ms", flush=True)
+
+
+def all_conv_latency():
+    # as a step runs them: all tails start together, the next round waits for all of them
+    torch.cuda.synchronize()
+    for e, g in conv:
+        lib.vv_graph_launch(g, e.sp)
+    torch.cuda.synchronize()
+
+
+print(f"conv tails, {B} dialogues started together, waited for (latency, incl. ~2 host syncs): {timeit(all_conv_latency, 30):.3f} ms", flush=True)
 e0 = m.engine
 g1 = {k[0]: g for k, g in e0._graphs.items()}
 print("single-dialogue graphs on the main engine:", {k: round(timeit(lambda g=g: lib.vv_graph_launch(g, e0.sp)), 3) for k, g in g1.items() if k in ("A", "B")})

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 512 : 64 * KSPLIT) void gemv_stream_k
     kval[u] = koff[u] < K;
     if (!kval[u]) koff[u] = 0;                    // any valid address; the activation there is forced to 0
   }
-  const bool reused = (a.flags & VV_LIN_W_REUSED) != 0;
+  const bool reused = (a.flags & VV_LIN_W_REUSED) != 0 || (opt & 16);    // opt bit 4 (tuning): every matrix with cacheable loads
   constexpr bool f8 = F8;                        // weight-only fp8 is its own instantiation: the bf16 kernels carry none of it
   // the first row group's weight loads are issued before the activation prologue so both latencies overlap
   const int gstride = (KSPLIT == 1) ? gridDim.x * nwv : gridDim.x;
