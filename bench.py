@@ -335,17 +335,20 @@ def batched_leg(model, cfg, args, batch=4, row_batch=None):
               max_length_times=max(2, -(-len(wls[0]["forced"]) // ids.shape[1]) + 1))
     if row_batch is not None:
         kw["row_batch"] = row_batch
-    n, dt = 0, None
-    for timed in (False, False, True):     # two warm-up calls: the first builds lanes / graphs, the second still grows the allocator's per-stream pools
-        torch.cuda.synchronize()           # (the first call's outputs are alive while it runs); a serving process is past both
-        t0 = time.perf_counter()
+    n, dts = 0, []
+    for timed in (False, False, True, True, True):   # two warm-up calls (lanes / graphs; the allocator's per-stream pools), then three timed ones:
+        torch.cuda.synchronize()                     # the loop enqueues ~1000 graph nodes per step from a few host threads and a call's rate
+        t0 = time.perf_counter()                     # moves by ~10 % with how they interleave - the median is reported, every run listed
         out = model.generate(**kw)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        if timed:
+            dts.append(time.perf_counter() - t0)
         n = sum(o.shape[-1] for o in out.speech_outputs)
     assert n == batch * args.frames * cfg.hop, (n, batch, args.frames)
+    dt = sorted(dts)[len(dts) // 2]
     rowb = (model.row_batch if row_batch is None else row_batch) and 2 < batch <= 4
     return dict(batch=batch, value=round(n / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3), row_batched=bool(rowb),
+                runs=[round(n / 24000.0 / d, 2) for d in dts],
                 note="one generate() call on a batch of dialogues of the headline shape, in lock step; " +
                      ("the dialogues are batched into the row dimension of the LLM and diffusion-head weight passes (one pass per frame for all of them, "
                       "vibevoice_rocm_amd/rowbatch.py), conv tokenizers per dialogue; lanes_value = the same call with one engine lane per dialogue; "

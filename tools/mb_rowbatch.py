@@ -15,6 +15,7 @@ m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_d
 m.set_ddpm_inference_steps(20)
 args = types.SimpleNamespace(frames=frames, voice_frames=203, cfg_scale=2.0)
 for batch in [int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('4', '3'))]:
-    for rb in (False, True, False, True):
+    order = (True, False, True, False, True) if (len(sys.argv) > 3 and sys.argv[3] == 'rbfirst') else (False, True, False, True)
+    for rb in order:
         r = bench.batched_leg(m, cfg, args, batch, row_batch=rb)
-        print(f"batch {batch} row_batch={rb}: {r['value']} audio-sec/s ({r['seconds']} s)", flush=True)
+        print(f"batch {batch} row_batch={rb}: {r['value']} audio-sec/s (runs {r['runs']})", flush=True)

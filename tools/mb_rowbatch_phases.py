@@ -65,6 +65,21 @@ def all_conv_latency():
 
 
 print(f"conv tails, {B} dialogues started together, waited for (latency, incl. ~2 host syncs): {timeit(all_conv_latency, 30):.3f} ms", flush=True)
+
+
+def host_cost(fn, n=3):
+    """host time of an enqueue (the call returns before the GPU runs the graph): few launches, so the queue never fills"""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    dt = (time.perf_counter() - t0) / n * 1e3
+    torch.cuda.synchronize()
+    return dt
+
+
+print(f"host time to enqueue: graph A {host_cost(lambda: lib.vv_graph_launch(gA, rb.sp)):.3f} ms, graph H {host_cost(lambda: lib.vv_graph_launch(gH, rb.sp)):.3f} ms, "
+      f"one conv tail {host_cost(lambda: lib.vv_graph_launch(conv[1][1], conv[1][0].sp)):.3f} ms", flush=True)
 e0 = m.engine
 g1 = {k[0]: g for k, g in e0._graphs.items()}
 print("single-dialogue graphs on the main engine:", {k: round(timeit(lambda g=g: lib.vv_graph_launch(g, e0.sp)), 3) for k, g in g1.items() if k in ("A", "B")})

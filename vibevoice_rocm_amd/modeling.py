@@ -140,6 +140,7 @@ class VibeVoiceForConditionalGenerationInference:
         self.speculative_frames = True
         # batches of 3..4 dialogues: one weight pass per frame for all of them (rowbatch.py) instead of one per dialogue (lanes)
         self.row_batch = os.environ.get("VV_ROW_BATCH", "1") != "0"
+        self.row_batch_min = int(os.environ.get("VV_ROW_BATCH_MIN", "3"))      # 2 dialogues: the lanes win (60 vs 58 audio-sec/s)
         self._rowbatch = {}
         # weight_quant="fp8": weight-only e4m3 companions for the per-frame weight-streaming GEMVs
         self.weight_quant = weight_quant
@@ -288,7 +289,7 @@ class VibeVoiceForConditionalGenerationInference:
                 raise NotImplementedError("refresh_negative=False is built for batch size 1 only")
             rb = kwargs.get("row_batch", self.row_batch)
             fn = self._generate_lockstep
-            if rb and int(os.environ.get("VV_ROW_BATCH_MIN", "3")) <= B <= 4 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
+            if rb and self.row_batch_min <= B <= 4 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
                 fn = self._generate_rowbatch      # dialogues batched into the row dimension of the LLM / diffusion-head weight passes (rowbatch.py)
             return fn(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
                                            forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
@@ -665,6 +666,7 @@ class VibeVoiceForConditionalGenerationInference:
                 drawn = torch.randn(2 * len(need), cfg.latent)[: len(need)] if need else None     # the reference's draw for n diffusing samples (:699)
                 rows = {b: (drawn[need.index(b)] if b in need else nz[b][frame[b]]) for b in todo}
                 rb.speech(todo, rows)
+            rb.flush()                     # the conv tails are enqueued from worker threads: the chunk copies below must queue behind them
             for b in diffusing:                                                                     # :571-670
                 with torch.cuda.stream(lanes[b].stream):
                     chunks[b].append(lanes[b].wav.clone())

@@ -66,6 +66,16 @@ class RowBatch:
         self._head_event = torch.cuda.Event()
         self._lane_event = [torch.cuda.Event() for _ in range(B)]
         self._lane_dirty = [False] * B      # lane b has work in flight that the next graph A must wait for
+        # A step is ~930 graph nodes (A 144, H 188, four conv tails of ~150) and the runtime enqueues them node by node at ~5 us each: from
+        # one host thread that is the GPU's step time, and the loop flips between GPU-bound (93 audio-sec/s) and host-bound (76) from call
+        # to call.  The tails go out from one worker thread per lane (the HIP calls release the GIL), as the lanes of the lock-step loop do.
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=B - 1)
+        self._jobs = []
+        import os
+        self.late_tails = os.environ.get("VV_RB_LATE_TAILS", "1") != "0"
+        self._timing = [] if os.environ.get("VV_RB_TIMING") else None      # debug: per-step HIP events (A start / A end / H end / tails end)
+        self._tcur = None
         self.kv = None
         self._kv_t = None
         self._graphs: Dict[tuple, int] = {}
@@ -89,7 +99,18 @@ class RowBatch:
         self._graphs = {}
 
     def close(self):
+        self._wait_jobs()
+        self._pool.shutdown()
         self._drop_graphs()
+
+    def flush(self):
+        """every launch handed to the worker threads is in its stream's queue"""
+        self._wait_jobs()
+
+    def _wait_jobs(self):
+        jobs, self._jobs = self._jobs, []
+        for j in jobs:
+            j.result()
 
     def _run(self, name: str, fn, *args):
         if not self.main.use_graphs:
@@ -254,6 +275,7 @@ class RowBatch:
 
     def _join_lanes(self):
         """the next graph A reads every lane's rows of x"""
+        self._wait_jobs()
         for b in range(1, self.B):
             if self._lane_dirty[b]:
                 self.stream.wait_event(self._lane_event[b])
@@ -269,7 +291,13 @@ class RowBatch:
         with torch.cuda.stream(self.stream):
             self._join_lanes()
             self._set_forced(forced)
+            if self._timing is not None:
+                self._tcur = dict(a0=torch.cuda.Event(enable_timing=True), a1=torch.cuda.Event(enable_timing=True), h1=None, t=[])
+                self._timing.append(self._tcur)
+                self._tcur["a0"].record(self.stream)
             self._run("A", self._seq_A, int(tok_start), int(tok_diff))
+            if self._timing is not None:
+                self._tcur["a1"].record(self.stream)
             self.token_host.copy_(self.token_dev, non_blocking=True)
             self._tok_event.record(self.stream)
 
@@ -288,16 +316,35 @@ class RowBatch:
             self.noise_dev.copy_(nh, non_blocking=True)
             self._run("H", self._seq_H, float(self.cfg_scale))
             self._head_event.record(self.stream)
-        for b in which:
+            if self._timing is not None and self._tcur is not None:
+                self._tcur["h1"] = torch.cuda.Event(enable_timing=True)
+                self._tcur["h1"].record(self.stream)
+
+        def tail(b):
             e = self.lanes[b]
+            torch.cuda.set_device(self.device)
             with torch.cuda.stream(e.stream):
-                if b:
-                    e.stream.wait_event(self._head_event)
                 e._run("RBconv", self._seq_conv, b, self.uid)
                 self._lane_done(b)
+                if self._timing is not None and self._tcur is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(e.stream)
+                    self._tcur["t"].append(ev)
+
+        # every cross-stream wait is issued HERE, by the thread that owns the main stream: a wait on an event of a stream that another thread is
+        # capturing (first use of a graph) is a capture-isolation error, and only this thread ever captures on the main stream
+        if self.late_tails:
+            self._head_event.synchronize()
+        for b in which:
+            if b:
+                self.lanes[b].stream.wait_event(self._head_event)
+                self._jobs.append(self._pool.submit(tail, b))
+        if 0 in which:
+            tail(0)             # dialogue 0's tail rides the main stream, behind H
 
     def embed(self, b: int):
         """next input of dialogue b = embed_tokens[its token], on its stream (after a rollback of that stream, if any)"""
+        self._wait_jobs()
         e = self.lanes[b]
         with torch.cuda.stream(e.stream):
             if b:
@@ -306,13 +353,29 @@ class RowBatch:
             self._lane_done(b)
 
     def rollback(self, b: int):
+        self._wait_jobs()
         self.lanes[b].rollback_speech_state()
 
     def reset_speech(self, b: int):
+        self._wait_jobs()
         e = self.lanes[b]
         with torch.cuda.stream(e.stream):
             e.reset_speech_caches()
 
     def synchronize(self):
+        self._wait_jobs()
         for e in self.lanes:
             e.stream.synchronize()
+        if self._timing:
+            import statistics
+            T = [t for t in self._timing if t["h1"] is not None and len(t["t"]) == self.B]
+            rows = []
+            for i in range(5, len(T) - 1):
+                t, nx = T[i], T[i + 1]
+                tails = max(t["h1"].elapsed_time(ev) for ev in t["t"])
+                rows.append((t["a0"].elapsed_time(t["a1"]), t["a1"].elapsed_time(t["h1"]), tails, t["a0"].elapsed_time(nx["a0"])))
+            if rows:
+                med = [statistics.median(r[k] for r in rows) for k in range(4)]
+                print(f"[rowbatch timing] {len(rows)} steps, medians: A {med[0]:.3f} ms, token copy + noise + H {med[1]:.3f} ms, tails after H {med[2]:.3f} ms, "
+                      f"step period {med[3]:.3f} ms (gap {med[3] - med[0] - med[1] - med[2]:.3f})", flush=True)
+            self._timing.clear()
