@@ -280,3 +280,45 @@ def test_generate_row_batch_7b_shapes_vs_lanes():
         assert err < 2e-2, f"7B shapes, dialogue {b}: waveform rel RMS {err:.3e}"
     del m
     torch.cuda.empty_cache()
+
+
+def test_generate_row_batch_mid_bf16_vs_oracle():
+    """The row-batched path against the CPU oracle (not only against the lanes): `mid` shapes (hidden 512, 3 layers, head D 512: the 8-row GEMV's
+    whole-row, split-K ticket and atomic forms all occur), bf16 weights, 3 dialogues of the 4-speaker prompt with different turn schedules and
+    noise in ONE generate() call; every dialogue against its own oracle run at the bf16 bar of the single-dialogue test (2e-2), with the lanes'
+    error next to it in the parity record."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import vv_oracle as O
+    from test_hip_configs import _four_speaker_inputs, _special
+    from vibevoice_rocm_amd.config import VVConfig
+    from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
+    from vibevoice_rocm_amd.synth import synth_state_dict
+    cfg = VVConfig.preset("mid")
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, 4321).items()}
+    sd_o = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+    V = cfg.vocab
+    ST, SE, SD, EOS = V - 4, V - 3, V - 2, V - 1
+    g = torch.Generator().manual_seed(29)
+    ids, sp_mask, wav, sm = _four_speaker_inputs(cfg, g)
+    forced = [([SD] * 4 + [SE, ST]) * 2 + [SD] * 4 + [SE, EOS], [SD] * 7 + [SE, ST] + [SD] * 3 + [SE, EOS], [SD] * 5 + [SE, EOS]]
+    noise = torch.randn(3, 12, cfg.latent, generator=g)
+    std_noise, eps_noise = torch.randn(4, generator=g), torch.randn(4, 4, cfg.ac_dim, generator=g)
+    _, conn = O.process_speech_inputs(sd_o, cfg.as_dict(), wav, sm, std_noise, eps_noise)
+    refs = [O.generate(sd_o, cfg.as_dict(), ids.tolist(), sp_mask, conn, _special(V), noise[b], cfg_scale=2.0, n_steps=20, forced_tokens=forced[b], bf16_t=True)
+            for b in range(3)]
+    m = VibeVoiceForConditionalGenerationInference(cfg, sd, device="cuda:0", torch_dtype=torch.bfloat16)
+    m.set_ddpm_inference_steps(20)
+    tok = _Tok(V)
+    tok.pad_id = 0
+    kw = dict(input_ids=ids[None].repeat(3, 1), attention_mask=torch.ones(3, ids.shape[0], dtype=torch.long), speech_tensors=wav.repeat(3, 1), speech_masks=sm.repeat(3, 1),
+              speech_input_mask=sp_mask[None].repeat(3, 1), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise,
+              speech_noise=(std_noise.repeat(3), eps_noise.repeat(3, 1, 1)))
+    outs = {rbm: m.generate(row_batch=rbm, **kw) for rbm in (True, False)}
+    assert 3 in m._rowbatch
+    for b in range(3):
+        want = torch.cat(refs[b].audio).numpy()
+        assert outs[True].sequences[b, ids.shape[0]: ids.shape[0] + len(forced[b])].tolist() == forced[b]
+        e_rows = rel_rms(outs[True].speech_outputs[b][0].float().cpu().numpy(), want, what=f"generate() 3 dialogues, mid bf16, ROW-BATCHED vs oracle, dialogue {b}")
+        e_lane = rel_rms(outs[False].speech_outputs[b][0].float().cpu().numpy(), want, what=f"generate() 3 dialogues, mid bf16, lanes vs oracle, dialogue {b}")
+        assert e_rows < 2e-2, f"row-batched dialogue {b}: waveform rel RMS {e_rows:.3e} vs oracle (lanes: {e_lane:.3e})"
