@@ -334,7 +334,7 @@ def test_batch_of_six_shares_streams_and_equals_singles(big):
     ids = torch.stack([torch.cat([torch.randint(0, 1000, (L - 1,), generator=g), torch.tensor([S])]) for _ in range(B)])
     forced = [[D] * (3 + (b % 3)) + [E, EOS] for b in range(B)]
     noise = torch.randn(B, 5, cfg.latent, generator=g)
-    out = m.generate(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise)
+    out = m.generate(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise, row_batch=False)
     assert len(m._lanes) >= B
     streams = [e.stream.cuda_stream for e in m._lanes[:B]]
     assert len(set(streams)) == M.LANES_IN_FLIGHT and streams[4] == streams[0] and streams[5] == streams[1]

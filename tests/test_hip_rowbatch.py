@@ -236,7 +236,7 @@ def test_generate_row_batch_vs_lanes(big):
                 got = torch.cat([c.reshape(-1) for c in st.get_stream(b)])
                 assert torch.equal(got, outs[rbm].speech_outputs[b][0].cpu()), f"sample {b}: streamed chunks"
             assert st.finished_flags == [True] * 4
-    assert 4 in m._rowbatch
+    assert (4, 0) in m._rowbatch
     assert outs[True].sequences.tolist() == outs[False].sequences.tolist()
     assert events[True] == events[False]
     for b in range(4):
@@ -273,7 +273,7 @@ def test_generate_row_batch_7b_shapes_vs_lanes():
     kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise)
     lanes = m.generate(row_batch=False, **kw)
     rows = m.generate(row_batch=True, **kw)
-    assert 3 in m._rowbatch and rows.sequences.tolist() == lanes.sequences.tolist()
+    assert (3, 0) in m._rowbatch and rows.sequences.tolist() == lanes.sequences.tolist()
     for b in range(3):
         err = rel_rms(rows.speech_outputs[b].float().cpu().numpy(), lanes.speech_outputs[b].float().cpu().numpy(),
                       what=f"generate() on 3 dialogues at 7B shapes bf16, row-batched vs lanes, waveform of dialogue {b}")
@@ -315,10 +315,35 @@ def test_generate_row_batch_mid_bf16_vs_oracle():
               speech_input_mask=sp_mask[None].repeat(3, 1), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise,
               speech_noise=(std_noise.repeat(3), eps_noise.repeat(3, 1, 1)))
     outs = {rbm: m.generate(row_batch=rbm, **kw) for rbm in (True, False)}
-    assert 3 in m._rowbatch
+    assert (3, 0) in m._rowbatch
     for b in range(3):
         want = torch.cat(refs[b].audio).numpy()
         assert outs[True].sequences[b, ids.shape[0]: ids.shape[0] + len(forced[b])].tolist() == forced[b]
         e_rows = rel_rms(outs[True].speech_outputs[b][0].float().cpu().numpy(), want, what=f"generate() 3 dialogues, mid bf16, ROW-BATCHED vs oracle, dialogue {b}")
         e_lane = rel_rms(outs[False].speech_outputs[b][0].float().cpu().numpy(), want, what=f"generate() 3 dialogues, mid bf16, lanes vs oracle, dialogue {b}")
         assert e_rows < 2e-2, f"row-batched dialogue {b}: waveform rel RMS {e_rows:.3e} vs oracle (lanes: {e_lane:.3e})"
+
+
+@pytest.mark.parametrize("B", [6, 8])
+def test_generate_two_row_batches_vs_lanes(big, B):
+    """5..8 dialogues: two row batches (3 + 3, 4 + 4) inside one lock-step loop, both on the main stream, the second batch's lanes sharing the HIP
+    streams of the first's - against the lanes: same sequences, waveforms to the bf16 noise floor."""
+    cfg, sd, m = big
+    tok = _Tok(cfg.vocab)
+    D, E, EOS, S = tok.speech_diffusion_id, tok.speech_end_id, tok.eos_token_id, tok.speech_start_id
+    g = torch.Generator().manual_seed(37 + B)
+    L = 40
+    ids = torch.stack([torch.cat([torch.randint(0, 1000, (L - 1,), generator=g), torch.tensor([S])]) for _ in range(B)])
+    forced = [[D] * (3 + (b % 3)) + ([E, S, D, D] if b == 1 else []) + [E, EOS] for b in range(B)]
+    noise = torch.randn(B, 8, cfg.latent, generator=g)
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise)
+    rows = m.generate(row_batch=True, **kw)
+    lanes = m.generate(row_batch=False, **kw)
+    n0 = (B + 1) // 2
+    assert (n0, 0) in m._rowbatch and (B // 2, n0) in m._rowbatch
+    assert rows.sequences.tolist() == lanes.sequences.tolist()
+    for b in range(B):
+        assert rows.speech_outputs[b].shape == lanes.speech_outputs[b].shape
+        err = rel_rms(rows.speech_outputs[b].float().cpu().numpy(), lanes.speech_outputs[b].float().cpu().numpy(),
+                      what=f"generate() on {B} dialogues (two row batches) 1.5B bf16 vs lanes, waveform of dialogue {b}")
+        assert err < 1e-2, f"{B} dialogues, dialogue {b}: waveform rel RMS {err:.3e}"

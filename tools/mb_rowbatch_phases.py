@@ -18,7 +18,7 @@ import os
 if os.environ.get("VV_GEMV_OPT"):
     m.engine.lib.vv_tune(b"gemv_opt", int(os.environ["VV_GEMV_OPT"]))
 bench.batched_leg(m, cfg, args, B, row_batch=True)
-rb = m._rowbatch[B]
+rb = m._rowbatch[(B, 0)]
 lib = rb.lib
 torch.cuda.synchronize()
 rb.set_active(0, True)

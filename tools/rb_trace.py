@@ -21,7 +21,7 @@ kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=wls[0]["
           speech_noise=(torch.cat([w["speech_noise"][0] for w in wls]), torch.cat([w["speech_noise"][1] for w in wls])),
           generation_config={"do_sample": False}, show_progress_bar=False, max_length_times=2, row_batch=True)
 m.generate(**kw)
-rb = m._rowbatch[4]
+rb = m._rowbatch[(4, 0)]
 lib = rb.lib
 for b in range(4):
     rb.set_active(b, False)

@@ -289,7 +289,7 @@ class VibeVoiceForConditionalGenerationInference:
                 raise NotImplementedError("refresh_negative=False is built for batch size 1 only")
             rb = kwargs.get("row_batch", self.row_batch)
             fn = self._generate_lockstep
-            if rb and self.row_batch_min <= B <= 4 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
+            if rb and self.row_batch_min <= B <= 8 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
                 fn = self._generate_rowbatch      # dialogues batched into the row dimension of the LLM / diffusion-head weight passes (rowbatch.py)
             return fn(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
                                            forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
@@ -542,28 +542,37 @@ class VibeVoiceForConditionalGenerationInference:
                            forced_tokens, noise, sde_noise, audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev):
         """The lock-step loop of `_generate_lockstep` with the B dialogues batched into the ROW dimension of the weight-heavy half of a frame
         (rowbatch.RowBatch: one Qwen2 decode step with 2 B rows, one diffusion sampling with 2 B rows; the conv tokenizers stay per dialogue on
-        their lanes' streams).  Token handling, the draws' order, speculation and rollback are the same; results agree with the lanes to the
-        rounding of the matrix-core GEMV (activations as bf16 hi + lo, ~2e-6 relative per product)."""
+        their lanes' streams).  5..8 dialogues run as TWO row batches inside the same loop, both on the main stream: each step enqueues A and H of
+        both, then the conv tails - a batch's tails overlap the other batch's A and H.  Token handling, the draws' order, speculation and rollback
+        are those of the lock-step loop; results agree with the lanes to the rounding of the matrix-core GEMV (activations as bf16 hi + lo,
+        ~2e-6 relative per product)."""
         from .rowbatch import RowBatch
         cfg = self.config
         B, Lp = input_ids.shape
         ST, SE, SD, EOS = special["speech_start"], special["speech_end"], special["speech_diffusion"], special["eos"]
         valid = [ST, SE, SD, EOS] + ([special["bos"]] if special.get("bos") is not None else [])
         lanes = [self._lane(b) for b in range(B)]
-        rb = self._rowbatch.get(B)
-        if rb is None:
-            rb = self._rowbatch[B] = RowBatch(lanes)
         keep = attention_mask.bool()
         L0 = keep.sum(-1).tolist()
         max_length = cfg.max_pos if max_new_tokens is None else Lp + int(max_new_tokens)            # :370-371 (padded length, as the reference)
         max_steps = min(max_length - Lp, int(max_length_times * Lp))                                # :420
         max_step_per_sample = [min(max_length - l, int(max_length_times * l)) for l in L0]          # :421
+        groups, rb_of, loc, off = [], {}, {}, 0
+        for n in ([B] if B <= 4 else [(B + 1) // 2, B // 2]):
+            idxs = list(range(off, off + n))
+            rb = self._rowbatch.get((n, off))
+            if rb is None:
+                rb = self._rowbatch[(n, off)] = RowBatch([lanes[b] for b in idxs], stream=self.engine.stream)
+            rb.begin(max(L0[b] for b in idxs) + max(max_steps, 1) + 8, valid, cfg_scale)
+            groups.append((rb, idxs))
+            for b in idxs:
+                rb_of[b], loc[b] = rb, b - off
+            off += n
         per_list = forced_tokens is not None and len(forced_tokens) > 0 and isinstance(forced_tokens[0], (list, tuple))
         ftok = [(forced_tokens[b] if per_list else forced_tokens) for b in range(B)]
         nz = [(noise[b] if (noise is not None and noise.dim() == 3) else noise) for b in range(B)]
-        rb.begin(max(L0) + max(max_steps, 1) + 8, valid, cfg_scale)
         x0s, off = [], 0
-        with torch.cuda.stream(rb.stream):
+        with torch.cuda.stream(self.engine.stream):
             for b in range(B):
                 x0 = self.engine.embed_ids(input_ids[b][keep[b]])
                 if speech_input_mask is not None and conn_all is not None:
@@ -593,7 +602,7 @@ class VibeVoiceForConditionalGenerationInference:
 
         def finish(b):
             finished[b] = True
-            rb.set_active(b, False)
+            rb_of[b].set_active(loc[b], False)
             if audio_streamer is not None:
                 deliver()
                 ours[b] = True
@@ -622,27 +631,39 @@ class VibeVoiceForConditionalGenerationInference:
             speculated = set()
             if step == 0:
                 for b in live:
-                    rb.prefill(b, x0s[b], chunk=getattr(self, "_prefill_chunk", 1024))
+                    rb_of[b].prefill(loc[b], x0s[b], chunk=getattr(self, "_prefill_chunk", 1024))
                 for b in live:
-                    toks[b] = rb.first_token(b, forced[b])
+                    toks[b] = rb_of[b].first_token(loc[b], forced[b])
                     if toks[b] == SD:
-                        rb.prefill(b, self.engine.embed_ids(torch.tensor([ST])), neg=True)
+                        rb_of[b].prefill(loc[b], self.engine.embed_ids(torch.tensor([ST])), neg=True)
             else:
-                # one graph A for every dialogue; in the steady state of the batch (every live dialogue diffusing, noise injected) the
-                # diffusion sampling and the conv tails go out speculatively behind it
-                spec = speculate and all(prev_tok[b] == SD and nz[b] is not None and frame[b] < len(nz[b]) for b in live)
-                rb.decode_begin(ST, SD, forced)
-                if spec:
-                    rb.speech(live, {b: nz[b][frame[b]] for b in live})
-                    speculated = set(live)
+                # graph A of every row batch; a batch in its steady state (every live dialogue diffusing, noise injected) gets its diffusion
+                # sampling enqueued speculatively behind it.  The conv tails follow once all A / H are queued: each batch's tails are enqueued
+                # when ITS sampler has finished (RowBatch.speech_tails) and run while the main stream works on the next batch
+                plan = []
+                for rb, idxs in groups:
+                    lv = [b for b in idxs if b in forced]
+                    if not lv:
+                        continue
+                    spec = speculate and all(prev_tok[b] == SD and nz[b] is not None and frame[b] < len(nz[b]) for b in lv)
+                    rb.decode_begin(ST, SD, {loc[b]: forced[b] for b in lv})
+                    if spec:
+                        rb.speech_begin([loc[b] for b in lv], {loc[b]: nz[b][frame[b]] for b in lv})
+                    plan.append((rb, lv, spec))
+                for rb, lv, spec in plan:
+                    if spec:
+                        rb.speech_tails([loc[b] for b in lv])
+                        speculated.update(lv)
                 deliver()                  # the previous step's chunks: their copies completed long before this step's tokens
-                tk = rb.decode_end()
-                toks = {b: tk[b] for b in live}
+                for rb, lv, spec in plan:
+                    tk = rb.decode_end()
+                    toks.update({b: tk[loc[b]] for b in lv})
             diffusing = []
             for b in live:
                 tok = toks[b]
+                rb = rb_of[b]
                 if b in speculated and tok != SD:
-                    rb.rollback(b)
+                    rb.rollback(loc[b])
                 prev_tok[b] = tok
                 seq[b].append(tok)
                 if tok == EOS:                                                                      # :517-526
@@ -655,18 +676,22 @@ class VibeVoiceForConditionalGenerationInference:
                     finish(b)
                     continue
                 if tok == SE:                                                                       # :540-544
-                    rb.reset_speech(b)
+                    rb.reset_speech(loc[b])
                 if tok == SD:
                     diffusing.append(b)
                 else:
-                    rb.embed(b)                                                                     # :567
+                    rb.embed(loc[b])                                                                # :567
             todo = [b for b in diffusing if b not in speculated]
             if todo:
                 need = [b for b in todo if nz[b] is None or frame[b] >= len(nz[b])]
                 drawn = torch.randn(2 * len(need), cfg.latent)[: len(need)] if need else None     # the reference's draw for n diffusing samples (:699)
                 rows = {b: (drawn[need.index(b)] if b in need else nz[b][frame[b]]) for b in todo}
-                rb.speech(todo, rows)
-            rb.flush()                     # the conv tails are enqueued from worker threads: the chunk copies below must queue behind them
+                for rb, idxs in groups:
+                    mine = [b for b in todo if rb_of[b] is rb]
+                    if mine:
+                        rb.speech([loc[b] for b in mine], {loc[b]: rows[b] for b in mine})
+            for rb, _ in groups:
+                rb.flush()                 # the conv tails are enqueued from worker threads: the chunk copies below must queue behind them
             for b in diffusing:                                                                     # :571-670
                 with torch.cuda.stream(lanes[b].stream):
                     chunks[b].append(lanes[b].wav.clone())
@@ -674,7 +699,8 @@ class VibeVoiceForConditionalGenerationInference:
                     pending.append((b, lanes[b].stage_chunk()))
                 frame[b] += 1
         deliver()
-        rb.synchronize()
+        for rb, _ in groups:
+            rb.synchronize()
         if audio_streamer is not None:
             audio_streamer.end()
         pad_id = getattr(tokenizer, "pad_id", None)

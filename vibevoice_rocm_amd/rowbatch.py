@@ -1,7 +1,7 @@
 """Row-batched decode for the dialogues of ONE generate() call (reference: the batched loop of modeling_vibevoice_inference.py:430-673).
 
 `Engine` lanes run B dialogues as B independent launch chains that each stream every LLM and diffusion-head weight once per frame.  Here the
-B dialogues (2 <= B <= 4) share ONE chain for the two weight-heavy parts of a frame:
+B dialogues (2 <= B <= 4 per RowBatch; generate() runs 5..8 as two of them in one loop) share ONE chain for the two weight-heavy parts of a frame:
 
   graph A   Qwen2 decode step with R = 2 B rows (dialogue b = rows {2 b: positive, 2 b + 1: negative} of x, lens and one KV cache with 2 B
             rows): every weight matrix is read once for all dialogues (5..8 rows: the matrix-core GEMV of csrc/vv_gemv_rows.hip on
@@ -24,16 +24,37 @@ from . import _lib as L
 from .engine import Engine
 
 _UID = itertools.count(1)
+# One worker thread per HIP stream, shared by every RowBatch of the process: two row batches of one generate() call (5..8 dialogues) put their
+# lanes on the same four streams, and a stream must never be fed by two host threads at once (the first use of a graph CAPTURES on the stream).
+# _JOBS: every launch handed to a worker and not yet known to be in its stream's queue.
+_STREAM_WORKERS: Dict[int, "object"] = {}
+_JOBS: List["object"] = []
+
+
+def _submit(stream: torch.cuda.Stream, fn, *args):
+    from concurrent.futures import ThreadPoolExecutor
+    w = _STREAM_WORKERS.get(stream.cuda_stream)
+    if w is None:
+        w = _STREAM_WORKERS[stream.cuda_stream] = ThreadPoolExecutor(max_workers=1)
+    _JOBS.append(w.submit(fn, *args))
+
+
+def _wait_all_jobs():
+    while _JOBS:
+        _JOBS.pop(0).result()
 
 
 class RowBatch:
-    def __init__(self, lanes: List[Engine]):
+    def __init__(self, lanes: List[Engine], stream: Optional[torch.cuda.Stream] = None):
+        """lanes: one Engine per dialogue (conv state, conv graphs, its stream).  stream: the stream graphs A and H run on (default: lanes[0]'s);
+        a lane whose stream IS that stream runs its conv tail inline behind H, the others fork / join through events."""
         self.lanes = lanes
         self.B = B = len(lanes)
         if not 2 <= B <= 4:
             raise L.VVError("row batching serves 2..4 dialogues per call")
         eng = self.main = lanes[0]
-        self.lib, self.cfg, self.device, self.stream = eng.lib, eng.cfg, eng.device, eng.stream
+        self.lib, self.cfg, self.device, self.stream = eng.lib, eng.cfg, eng.device, (stream or eng.stream)
+        self._on_main = [e.stream.cuda_stream == self.stream.cuda_stream for e in lanes]
         if eng.dtype != torch.bfloat16 or eng.kv_dtype != torch.bfloat16 or eng.w.quant is not None:
             raise L.VVError("row batching needs bf16 weights and a bf16 KV cache")
         self.uid = next(_UID)
@@ -66,12 +87,8 @@ class RowBatch:
         self._head_event = torch.cuda.Event()
         self._lane_event = [torch.cuda.Event() for _ in range(B)]
         self._lane_dirty = [False] * B      # lane b has work in flight that the next graph A must wait for
-        # A step is ~930 graph nodes (A 144, H 188, four conv tails of ~150) and the runtime enqueues them node by node at ~5 us each: from
-        # one host thread that is the GPU's step time, and the loop flips between GPU-bound (93 audio-sec/s) and host-bound (76) from call
-        # to call.  The tails go out from one worker thread per lane (the HIP calls release the GIL), as the lanes of the lock-step loop do.
-        from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=B - 1)
-        self._jobs = []
+        # the conv tails go out from one worker thread per lane stream (a hipGraph launch costs the host ~0.08 ms: four in a row would delay the
+        # last tail by a quarter of a millisecond; the HIP calls release the GIL), see _STREAM_WORKERS
         import os
         self.late_tails = os.environ.get("VV_RB_LATE_TAILS", "1") != "0"
         self._timing = [] if os.environ.get("VV_RB_TIMING") else None      # debug: per-step HIP events (A start / A end / H end / tails end)
@@ -100,7 +117,6 @@ class RowBatch:
 
     def close(self):
         self._wait_jobs()
-        self._pool.shutdown()
         self._drop_graphs()
 
     def flush(self):
@@ -108,9 +124,7 @@ class RowBatch:
         self._wait_jobs()
 
     def _wait_jobs(self):
-        jobs, self._jobs = self._jobs, []
-        for j in jobs:
-            j.result()
+        _wait_all_jobs()
 
     def _run(self, name: str, fn, *args):
         if not self.main.use_graphs:
@@ -137,9 +151,10 @@ class RowBatch:
         cfg, eng, B = self.cfg, self.main, self.B
         s_max = (int(s_max) + 63) // 64 * 64
         self.cfg_scale = float(cfg_scale)
-        for e in self.lanes[1:]:
-            e.sync_in()
-            e.stream.wait_stream(self.stream)
+        for b, e in enumerate(self.lanes):
+            if not self._on_main[b]:
+                e.sync_in()
+                e.stream.wait_stream(self.stream)
         with torch.cuda.stream(self.stream):
             if self.kv is None or self.kv.s_max < s_max:
                 shape = (cfg.layers, 2 * B, cfg.kv_heads, s_max, cfg.head_dim)
@@ -171,6 +186,8 @@ class RowBatch:
             self.frame_ctr.zero_()
             self.forced_dev.fill_(-1)
             self.active_dev.fill_(1)
+            self.forced_host.fill_(-1)      # the pinned mirrors are uploaded WHOLE whenever one entry changes: they must not carry the last call's values
+            self.active_host.fill_(1)
             self._forced_val = [-1] * B
             self._active_val = [1] * B
         for e in self.lanes:
@@ -276,13 +293,13 @@ class RowBatch:
     def _join_lanes(self):
         """the next graph A reads every lane's rows of x"""
         self._wait_jobs()
-        for b in range(1, self.B):
+        for b in range(self.B):
             if self._lane_dirty[b]:
                 self.stream.wait_event(self._lane_event[b])
                 self._lane_dirty[b] = False
 
     def _lane_done(self, b):
-        if b:
+        if not self._on_main[b]:
             self._lane_event[b].record(self.lanes[b].stream)
             self._lane_dirty[b] = True
 
@@ -307,6 +324,11 @@ class RowBatch:
 
     def speech(self, which: List[int], noise: Dict[int, torch.Tensor]):
         """Diffusion sampling for the whole batch (graph H), then the conv tail of the dialogues in `which`, each on its own stream."""
+        self.speech_begin(which, noise)
+        self.speech_tails(which)
+
+    def speech_begin(self, which: List[int], noise: Dict[int, torch.Tensor]):
+        """noise upload + graph H on the main stream"""
         cfg = self.cfg
         with torch.cuda.stream(self.stream):
             self._noise_k ^= 1
@@ -320,6 +342,11 @@ class RowBatch:
                 self._tcur["h1"] = torch.cuda.Event(enable_timing=True)
                 self._tcur["h1"].record(self.stream)
 
+    def speech_tails(self, which: List[int]):
+        """The conv tails of the dialogues in `which`, enqueued once H HAS FINISHED (late_tails): a lane queue that sits on a cross-stream wait
+        while the main queue runs A and H slows every dependent launch there by ~6 us (graph A 1.35 -> 2.28 ms, H 1.72 -> 2.9 ms, measured with
+        VV_RB_TIMING=1), so the lanes' queues stay EMPTY until their work can run.  With several row batches in one loop (more than 4 dialogues)
+        the caller enqueues every batch's A and H first and the tails afterwards: a batch's tails then overlap the next batch's A and H."""
         def tail(b):
             e = self.lanes[b]
             torch.cuda.set_device(self.device)
@@ -335,19 +362,23 @@ class RowBatch:
         # capturing (first use of a graph) is a capture-isolation error, and only this thread ever captures on the main stream
         if self.late_tails:
             self._head_event.synchronize()
+        self._wait_jobs()       # another row batch's worker may still be feeding (first use: capturing on) one of these streams
+        inline = []
         for b in which:
-            if b:
+            if self._on_main[b]:
+                inline.append(b)
+            else:
                 self.lanes[b].stream.wait_event(self._head_event)
-                self._jobs.append(self._pool.submit(tail, b))
-        if 0 in which:
-            tail(0)             # dialogue 0's tail rides the main stream, behind H
+                _submit(self.lanes[b].stream, tail, b)
+        for b in inline:
+            tail(b)             # this dialogue's tail rides the main stream, behind H
 
     def embed(self, b: int):
         """next input of dialogue b = embed_tokens[its token], on its stream (after a rollback of that stream, if any)"""
         self._wait_jobs()
         e = self.lanes[b]
         with torch.cuda.stream(e.stream):
-            if b:
+            if not self._on_main[b]:
                 e.stream.wait_event(self._tok_event)
             e._run("RBembed", self._seq_embed, b, self.uid)
             self._lane_done(b)
