@@ -650,11 +650,11 @@ class VibeVoiceForConditionalGenerationInference:
                     if spec:
                         rb.speech_begin([loc[b] for b in lv], {loc[b]: nz[b][frame[b]] for b in lv})
                     plan.append((rb, lv, spec))
+                deliver()                  # the previous step's chunks (their copies completed long ago), before the host waits for a sampler
                 for rb, lv, spec in plan:
                     if spec:
                         rb.speech_tails([loc[b] for b in lv])
                         speculated.update(lv)
-                deliver()                  # the previous step's chunks: their copies completed long before this step's tokens
                 for rb, lv, spec in plan:
                     tk = rb.decode_end()
                     toks.update({b: tk[loc[b]] for b in lv})

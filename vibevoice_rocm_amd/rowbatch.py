@@ -11,11 +11,13 @@ B dialogues (2 <= B <= 4 per RowBatch; generate() runs 5..8 as two of them in on
 
 The conv tokenizers (acoustic decode, semantic encode) and the connectors stay per dialogue - each has its own streaming state - and run as
 B concurrent hipGraphs on the lanes' streams between H and the next A (events fork / join them), exactly the launch sequences the lanes use.
-The host loop, token state machine, speculation and rollback are those of the lock-step loop (modeling.py)."""
+They are enqueued only once H has finished: a lane queue that sits on a cross-stream wait while the main queue runs A and H slows every dependent
+launch there.  The host loop, token state machine, speculation and rollback are those of the lock-step loop (modeling.py)."""
 from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -89,7 +91,6 @@ class RowBatch:
         self._lane_dirty = [False] * B      # lane b has work in flight that the next graph A must wait for
         # the conv tails go out from one worker thread per lane stream (a hipGraph launch costs the host ~0.08 ms: four in a row would delay the
         # last tail by a quarter of a millisecond; the HIP calls release the GIL), see _STREAM_WORKERS
-        import os
         self.late_tails = os.environ.get("VV_RB_LATE_TAILS", "1") != "0"
         self._timing = [] if os.environ.get("VV_RB_TIMING") else None      # debug: per-step HIP events (A start / A end / H end / tails end)
         self._tcur = None
