@@ -33,8 +33,10 @@ enum { VV_OK = 0, VV_E_ARG = -1, VV_E_HIP = -2, VV_E_UNSUPPORTED = -3 };
 enum { VV_PRO_NONE = 0, VV_PRO_RMSNORM = 1, VV_PRO_SILU = 2 };
 enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
 /* vv_lin_args.flags: bf16 activation hand-off between two matrix-core GEMMs (x / out point at bf16 [m, ld] arrays, no
- * prologue on a bf16 x), and a hint that the weights are re-read soon (keep them cacheable instead of streaming them
- * non-temporally: the diffusion head's matrices are reused by every one of the N solver steps of a frame) */
+ * prologue on a bf16 x), a hint that the weights are re-read soon (keep them cacheable instead of streaming them
+ * non-temporally: the diffusion head's matrices are reused by every one of the N solver steps of a frame), and
+ * VV_LIN_W_FRAG: w / w2 point at the fragment-major copies of the matrices (vv_llm_layer.f_*; 5..8 rows, bf16, n % 16 == 0,
+ * k % 32 == 0 - any other call with this flag is an error) */
 enum { VV_LIN_X_BF16 = 1, VV_LIN_OUT_BF16 = 2, VV_LIN_W_REUSED = 4, VV_LIN_W_FRAG = 8 };
 
 const char* vv_last_error(void);

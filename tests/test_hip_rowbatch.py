@@ -347,3 +347,19 @@ def test_generate_two_row_batches_vs_lanes(big, B):
         err = rel_rms(rows.speech_outputs[b].float().cpu().numpy(), lanes.speech_outputs[b].float().cpu().numpy(),
                       what=f"generate() on {B} dialogues (two row batches) 1.5B bf16 vs lanes, waveform of dialogue {b}")
         assert err < 1e-2, f"{B} dialogues, dialogue {b}: waveform rel RMS {err:.3e}"
+
+
+def test_frag_flag_is_rejected_where_nothing_reads_that_layout(lib):
+    """VV_LIN_W_FRAG on a call the 5..8-row GEMV does not take (2 rows; no split-K scratch for a long-K shape) is an error, never a silent read of
+    a fragment-major matrix as if it were row-major."""
+    from vibevoice_rocm_amd import _lib as L
+    x = torch.randn(8, 8960, device="cuda")
+    w = _frag((torch.randn(1536, 8960, device="cuda") / 90).bfloat16())
+    out = torch.zeros(8, 1536, device="cuda")
+    a = L.LinArgs()
+    a.x, a.ldx, a.n, a.k, a.wdt = x.data_ptr(), 8960, 1536, 8960, L.VV_BF16
+    a.w, a.flags, a.out, a.ldo = w.data_ptr(), L.LIN_W_FRAG, out.data_ptr(), 1536
+    for m in (2, 8):
+        a.m = m
+        assert lib.vv_linear(C.byref(a), torch.cuda.current_stream().cuda_stream) != 0, f"m={m}"
+        assert b"FRAG" in lib.vv_last_error()

@@ -540,6 +540,8 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
       const int rc = vv_launch_gemv_rows(a, g_rows_part, G_ROWS_PART_FLOATS, g_rows_tk, G_ROWS_TICKETS, s);
       if (rc) return rc < 0 ? rc : 0;
     }
+    if (a.flags & VV_LIN_W_FRAG)                                // only the 5..8-row matrix-core GEMV reads the fragment-major layout
+      return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: VV_LIN_W_FRAG weights are read by the 5..8-row GEMV only (m=%d n=%d k=%d not covered)", a.m, a.n, a.k);
     if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
       // 5..8 rows not covered above: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
@@ -638,6 +640,8 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   if (a->act != VV_ACT_SWIGLU && a->w2) return vv_set_error(VV_E_ARG, "vv_linear: w2 given without SWIGLU");
   if (a->mod_scale && (!a->mod_shift || a->pro != VV_PRO_RMSNORM)) return vv_set_error(VV_E_ARG, "vv_linear: modulate needs RMSNORM prologue and shift");
   if (a->m > 8 && a->ldx == 0) return vv_set_error(VV_E_ARG, "vv_linear: broadcast rows (ldx=0) only for m<=8");
+  if ((a->flags & VV_LIN_W_FRAG) && (a->wdt != VV_BF16 || a->m < 5 || a->m > 8 || a->n % 16 || a->k % 32))
+    return vv_set_error(VV_E_ARG, "vv_linear: VV_LIN_W_FRAG needs bf16 weights, 5..8 rows, n %% 16 == 0 and k %% 32 == 0");
   if ((a->flags & (VV_LIN_X_BF16 | VV_LIN_OUT_BF16)) && (a->wdt != VV_BF16 || a->m <= 8 || a->k % 16))
     return vv_set_error(VV_E_ARG, "vv_linear: bf16 activation hand-off needs bf16 weights, m > 8 and k %% 16 == 0");
   hipStream_t s = (hipStream_t)stream;
