@@ -289,7 +289,7 @@ def concurrent_leg(model, cfg, sd, dtype, device, args, streams=3):
     import gc
     import threading
     from vibevoice_rocm_amd.modeling import VibeVoiceForConditionalGenerationInference
-    model._lanes = model._lanes[:1]          # lanes of an earlier batched leg hand their HIP streams back (engine.py, _IDLE_STREAMS)
+    model.release_lanes()                    # lanes / row batches of an earlier batched leg hand their HIP streams back (engine.py, _IDLE_STREAMS)
     gc.collect()
     models = [model] + [VibeVoiceForConditionalGenerationInference(cfg, sd, device=device, torch_dtype=dtype, use_graphs=not args.no_graphs)
                         for _ in range(streams - 1)]

@@ -327,6 +327,16 @@ class VibeVoiceForConditionalGenerationInference:
 
 
     # ---- batches: lock step over samples (modeling_vibevoice_inference.py:430-673 with batch_size > 1) ---------------------
+    def release_lanes(self) -> None:
+        """Drop the engines of earlier batched calls (lanes, row batches): their HIP streams go back to the recycle pool (engine.py, _IDLE_STREAMS)."""
+        for rb in self._rowbatch.values():
+            rb.close()
+        self._rowbatch = {}
+        for e in self._lanes[1:]:
+            e.stream.synchronize()
+            e.close()
+        self._lanes = self._lanes[:1]
+
     def _lane(self, b: int) -> Engine:
         while len(self._lanes) <= b:
             n = len(self._lanes)             # lanes past LANES_IN_FLIGHT share the stream of lane n % LANES_IN_FLIGHT: see _generate_lockstep
