@@ -221,10 +221,13 @@ class Engine:
                                          L.ptr(cache_rows), out.data_ptr(), out.stride(0), self._llm_ws.data_ptr(), self.sp),
                  "vv_llm_forward")
 
-    def prefill(self, embeds: torch.Tensor, row: int = 0, pos0: int = 0, chunk: int = 1024) -> None:
+    def prefill(self, embeds: torch.Tensor, row: int = 0, pos0: int = 0, chunk: int = 1024, neg_embed: Optional[torch.Tensor] = None) -> None:
         """Prompt prefill on cache row `row`: embeds [L0, H] fp32 -> self.hidden2[row] = last hidden state; lens[row] = pos0+L0.
         Prompts longer than `chunk` rows run as ceil(L0 / chunk) EQUAL chunks (rounded up to 32 rows): a short trailing chunk would stream
-        every weight matrix once more for a handful of rows (1 040 tokens as 1 024 + 16 cost 18.5 ms, as 2 x 520 they cost 12)."""
+        every weight matrix once more for a handful of rows (1 040 tokens as 1 024 + 16 cost 18.5 ms, as 2 x 520 they cost 12).
+        neg_embed [1, H]: the negative branch's one-token prompt (a single speech_start, modeling_vibevoice_inference.py:377-381) rides along as
+        one more row of the last chunk - cache row 1, position 0 - instead of a weight pass of its own (1.1 ms of the first chunk's latency);
+        hidden2[1] then holds its state and the CALLER sets lens[1] = 1 if the branch is in use (`commit_negative_prompt`)."""
         L0 = embeds.shape[0]
         n_chunks = max(1, -(-L0 // max(1, chunk)))
         size = -(-L0 // n_chunks)
@@ -233,12 +236,27 @@ class Engine:
             for c0 in range(0, L0, size):
                 c1 = min(L0, c0 + size)
                 n = c1 - c0
-                lens = torch.arange(pos0 + c0, pos0 + c1, dtype=torch.int32, device=self.device)
-                rows = torch.full((n,), row, dtype=torch.int32, device=self.device)
-                out = torch.empty(n, self.cfg.hidden, dtype=torch.float32, device=self.device)
-                self.llm_forward(embeds[c0:c1].contiguous(), lens, rows, out)
-            self.hidden2[row].copy_(out[-1])
+                last = c1 == L0 and neg_embed is not None
+                lens = torch.arange(pos0 + c0, pos0 + c1 + (1 if last else 0), dtype=torch.int32, device=self.device)
+                rows = torch.full((n + (1 if last else 0),), row, dtype=torch.int32, device=self.device)
+                x = embeds[c0:c1].contiguous()
+                if last:
+                    lens[-1] = 0
+                    rows[-1] = 1
+                    x = torch.cat([x, neg_embed.to(x.dtype).reshape(1, -1)])
+                out = torch.empty(x.shape[0], self.cfg.hidden, dtype=torch.float32, device=self.device)
+                self.llm_forward(x, lens, rows, out)
+            if neg_embed is not None:
+                self.hidden2[row].copy_(out[-2])
+                self.hidden2[1].copy_(out[-1])
+            else:
+                self.hidden2[row].copy_(out[-1])
             self.lens[row] = pos0 + L0
+
+    def commit_negative_prompt(self):
+        """the negative branch consumed its one-token prompt (see prefill, neg_embed)"""
+        with torch.cuda.stream(self.stream):
+            self.lens[1] = 1
 
     def _logits(self):
         a = L.LinArgs()

@@ -445,11 +445,11 @@ class VibeVoiceForConditionalGenerationInference:
             speculated = set()
             if step == 0:
                 for b in live:
-                    lanes[b].prefill(x0s[b], row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024))
+                    lanes[b].prefill(x0s[b], row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024), neg_embed=lanes[b].embed_ids(torch.tensor([ST])))
                 for b in live:
                     toks[b] = lanes[b].first_token(ST, SD, forced[b], sample_fn)
                     if toks[b] == SD:
-                        lanes[b].prefill(lanes[b].embed_ids(torch.tensor([ST])), row=1, pos0=0)
+                        lanes[b].commit_negative_prompt()
             elif sample_fn is not None:
                 for b in live:
                     toks[b] = lanes[b].step_decode(ST, SD, forced[b], sample_fn)
@@ -640,12 +640,13 @@ class VibeVoiceForConditionalGenerationInference:
             toks = {}
             speculated = set()
             if step == 0:
+                st_embed = self.engine.embed_ids(torch.tensor([ST]))
                 for b in live:
-                    rb_of[b].prefill(loc[b], x0s[b], chunk=getattr(self, "_prefill_chunk", 1024))
+                    rb_of[b].prefill(loc[b], x0s[b], chunk=getattr(self, "_prefill_chunk", 1024), neg_embed=st_embed)
                 for b in live:
                     toks[b] = rb_of[b].first_token(loc[b], forced[b])
                     if toks[b] == SD:
-                        rb_of[b].prefill(loc[b], self.engine.embed_ids(torch.tensor([ST])), neg=True)
+                        rb_of[b].commit_negative(loc[b])
             else:
                 # graph A of every row batch; a batch in its steady state (every live dialogue diffusing, noise injected) gets its diffusion
                 # sampling enqueued speculatively behind it.  The conv tails follow once all A / H are queued: each batch's tails are enqueued
@@ -787,11 +788,11 @@ class VibeVoiceForConditionalGenerationInference:
             forced = forced_tokens[step] if (forced_tokens is not None and step < len(forced_tokens)) else None
             speculated = False
             if step == 0:
-                eng.prefill(x0, row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024))
+                # the negative branch's prompt, a single speech_start (:377-381), is one more row of the prompt prefill (cache row 1, position 0)
+                eng.prefill(x0, row=0, pos0=0, chunk=getattr(self, "_prefill_chunk", 1024), neg_embed=eng.embed_ids(torch.tensor([ST])))
                 tok = eng.first_token(ST_dev, SD, forced, sample_fn)
                 if tok == SD or not refresh_negative:
-                    # the negative branch of step 0 consumes its own prompt, a single speech_start (:377-381)
-                    eng.prefill(eng.embed_ids(torch.tensor([ST])), row=1, pos0=0)
+                    eng.commit_negative_prompt()         # the branch is in use from step 0 on (otherwise the row is overwritten by the next speech_start)
             elif speculate and prev_tok == SD and (pending_nz is not None or ((noise is None or frame < len(noise)) and
                                                                             (sde_noise is None or frame < len(sde_noise)))):
                 # steady state of a dialogue: the frame's diffusion tail is enqueued right behind the LLM step, the host waits

@@ -196,28 +196,43 @@ class RowBatch:
                 e.reset_speech_caches()
         self._lane_dirty = [False] * B
 
-    def prefill(self, b: int, embeds: torch.Tensor, neg: bool = False, chunk: int = 1024):
-        """Prompt prefill of dialogue b on cache row 2 b (neg: 2 b + 1), on the main stream; hidden[row] = last hidden state."""
+    def prefill(self, b: int, embeds: torch.Tensor, neg: bool = False, chunk: int = 1024, neg_embed: Optional[torch.Tensor] = None):
+        """Prompt prefill of dialogue b on cache row 2 b (neg: 2 b + 1), on the main stream; hidden[row] = last hidden state.  neg_embed [1, H]:
+        the negative branch's one-token prompt rides along as one more row of the last chunk (cache row 2 b + 1, position 0; Engine.prefill);
+        `commit_negative` then puts the branch in use."""
         row = 2 * b + (1 if neg else 0)
         L0 = embeds.shape[0]
         n_chunks = max(1, -(-L0 // max(1, chunk)))
         size = -(-L0 // n_chunks)
         size = min(chunk, (size + 31) // 32 * 32) if n_chunks > 1 else L0
         with torch.cuda.stream(self.stream):
-            if max(size, 1) > self._pf_rows:
-                self._pf_rows = max(size, 64)
+            if max(size, 1) + 1 > self._pf_rows:
+                self._pf_rows = max(size + 1, 64)
                 self._pf_ws = torch.empty(self.lib.vv_llm_ws_bytes(C.byref(self.main.w.llm), self._pf_rows), dtype=torch.uint8, device=self.device)
             for c0 in range(0, L0, size):
                 c1 = min(L0, c0 + size)
-                n = c1 - c0
-                lens = torch.arange(c0, c1, dtype=torch.int32, device=self.device)
+                last = c1 == L0 and neg_embed is not None
+                n = c1 - c0 + (1 if last else 0)
+                lens = torch.arange(c0, c0 + n, dtype=torch.int32, device=self.device)
                 rows = torch.full((n,), row, dtype=torch.int32, device=self.device)
-                out = torch.empty(n, self.cfg.hidden, dtype=torch.float32, device=self.device)
                 xe = embeds[c0:c1].contiguous()
+                if last:
+                    lens[-1] = 0
+                    rows[-1] = 2 * b + 1
+                    xe = torch.cat([xe, neg_embed.to(xe.dtype).reshape(1, -1)])
+                out = torch.empty(n, self.cfg.hidden, dtype=torch.float32, device=self.device)
                 self._ck(self.lib.vv_llm_forward(C.byref(self.main.w.llm), C.byref(self.kv), xe.data_ptr(), xe.stride(0), n, lens.data_ptr(), rows.data_ptr(),
                                                  out.data_ptr(), out.stride(0), self._pf_ws.data_ptr(), self.sp), "vv_llm_forward")
-            self.hidden[row].copy_(out[-1])
+            if neg_embed is not None:
+                self.hidden[row].copy_(out[-2])
+                self.hidden[2 * b + 1].copy_(out[-1])
+            else:
+                self.hidden[row].copy_(out[-1])
             self.lens[row] = L0
+
+    def commit_negative(self, b: int):
+        with torch.cuda.stream(self.stream):
+            self.lens[2 * b + 1] = 1
 
     def first_token(self, b: int, forced: Optional[int]) -> int:
         """Token selection right after the prefill of dialogue b (hidden[2 b] holds its last prompt state)."""
