@@ -81,9 +81,10 @@ class Engine:
         self._tok_event = torch.cuda.Event()
         # streaming delivery: a frame's 3200 samples go device -> pinned ring asynchronously, an event per
         # slot says when the host may hand them to the AudioStreamer; generate() never blocks the launch queue on a D2H copy
-        self._ring = [torch.zeros(cfg.hop, dtype=torch.float32).pin_memory() for _ in range(4)]
-        self._ring_ev = [torch.cuda.Event() for _ in range(4)]
+        self._ring = [torch.zeros(cfg.hop, dtype=torch.float32).pin_memory() for _ in range(8)]     # 8 slots: <= 3 chunks wait for delivery, a
+        self._ring_ev = [torch.cuda.Event() for _ in range(8)]                                       # mis-speculated frame burns one
         self._ring_n = 0
+        self.spec_slot = None
         with torch.cuda.stream(self.stream):
             self._state_snap = torch.empty_like(self.w.state_blob())
         self.scheduler = DPMSolverMultistepScheduler(num_train_timesteps=cfg.ddpm_steps, beta_schedule=cfg.beta_schedule,
@@ -314,6 +315,40 @@ class Engine:
         self._ck(lib.vv_connector_pair(C.byref(w.ac_conn), C.byref(w.sem_conn), self.latent.data_ptr(), self.sem.data_ptr(), self.x2.data_ptr(), cfg.hidden, 2,
                                        self.conn_ws.data_ptr(), self.sp), "connectors")
 
+    def _seq_B1(self, cfg_scale):
+        """first half of _seq_B, up to the frame's audio (streaming delivery: the chunk's D2H copy goes out between the halves)"""
+        lib, w, cfg = self.lib, self.w, self.cfg
+        blob = w.state_blob()
+        self._ck(lib.vv_copy_rows(blob.data_ptr(), blob.numel(), self._state_snap.data_ptr(), blob.numel(), 1, blob.numel(), self.sp), "snapshot")
+        self._ck(lib.vv_head_sample(C.byref(w.head), self.hidden2.data_ptr(), cfg.hidden, self.noise_dev.data_ptr(),
+                                    self.temb.data_ptr(), self._coefs, self.n_steps, cfg_scale, self.latent.data_ptr(),
+                                    self._head_ws.data_ptr(), self.sde_noise_dev.data_ptr() if self.sde else None, self.sp), "vv_head_sample")
+        self._ck(lib.vv_decoder_forward(C.byref(w.dec), self.latent.data_ptr(), 1, 1.0 / w.speech_scale, -w.speech_bias,
+                                        self.wav.data_ptr(), self._dec_ws.data_ptr(), self.sp), "vv_decoder_forward")
+
+    def _seq_B2(self):
+        """second half of _seq_B: semantic re-encode of the frame and the next step's input embedding"""
+        lib, w, cfg = self.lib, self.w, self.cfg
+        self._ck(lib.vv_encoder_forward(C.byref(w.sem), self.wav.data_ptr(), cfg.hop, self.sem.data_ptr(),
+                                        self._sem_ws.data_ptr(), self.sp), "vv_encoder_forward")
+        self._ck(lib.vv_connector_pair(C.byref(w.ac_conn), C.byref(w.sem_conn), self.latent.data_ptr(), self.sem.data_ptr(), self.x2.data_ptr(), cfg.hidden, 2,
+                                       self.conn_ws.data_ptr(), self.sp), "connectors")
+
+    def _speech(self, cfg_scale: float, stage: bool) -> Optional[int]:
+        """Phase B on the current stream.  stage: a consumer is waiting for the audio (AudioStreamer) - the frame runs as two graphs and the
+        chunk's device -> pinned copy is enqueued BETWEEN them, as soon as the acoustic decoder has produced it: the chunk reaches the host
+        ~0.5 ms earlier than behind the semantic encoder and the connectors (which only the NEXT step needs).  Returns the ring slot."""
+        if not stage:
+            self._run("B", self._seq_B, cfg_scale)
+            return None
+        self._run("B1", self._seq_B1, cfg_scale)
+        k = self._ring_n % len(self._ring)
+        self._ring_n += 1
+        self._ring[k].copy_(self.wav, non_blocking=True)
+        self._ring_ev[k].record(self.stream)
+        self._run("B2", self._seq_B2)
+        return k
+
     def _seq_C(self):
         """next embedding = embed_tokens[token] for both rows (modeling_vibevoice_inference.py:567)."""
         cfg = self.cfg
@@ -407,15 +442,16 @@ class Engine:
             sh.copy_(sde_noise.reshape(self.n_steps, -1)[:, : self.cfg.latent])
             self.sde_noise_dev.copy_(sh, non_blocking=True)
 
-    def step_speech(self, noise: torch.Tensor, sde_noise: Optional[torch.Tensor] = None):
+    def step_speech(self, noise: torch.Tensor, sde_noise: Optional[torch.Tensor] = None, stage: bool = False) -> Optional[int]:
         """Phase B.  `noise` is the CPU fp32 [latent] row the reference would have drawn (modeling_vibevoice_inference.py:699),
-        `sde_noise` [n_steps, latent] the variance noise of the SDE solver's steps (dpm_solver.py:993-998), if that solver is set."""
+        `sde_noise` [n_steps, latent] the variance noise of the SDE solver's steps (dpm_solver.py:993-998), if that solver is set.
+        stage: also enqueue the chunk's copy to the pinned ring as soon as the decoder is done (see _speech); returns the slot."""
         with torch.cuda.stream(self.stream):
             self._upload_noise(noise, sde_noise)
-            self._run("B", self._seq_B, float(self.cfg_scale))
+            return self._speech(float(self.cfg_scale), stage)
 
     def step_decode_speculative(self, tok_start: int, tok_diff: int, forced: Optional[int], noise: torch.Tensor,
-                                sde_noise: Optional[torch.Tensor] = None, on_enqueued=None) -> int:
+                                sde_noise: Optional[torch.Tensor] = None, on_enqueued=None, stage: bool = False) -> int:
         """Phase A, then phase B enqueued right behind it ON THE ASSUMPTION that the token is speech_diffusion (the steady state
         of a dialogue), then one host wait on the token alone.  The GPU therefore never idles between A and B while the host
         wakes up and decides; if the token turns out to be something else the caller rolls the speech state back
@@ -426,7 +462,7 @@ class Engine:
             self.token_host.copy_(self.token_dev, non_blocking=True)
             self._tok_event.record(self.stream)
             self._upload_noise(noise, sde_noise)
-            self._run("B", self._seq_B, float(self.cfg_scale))
+            self.spec_slot = self._speech(float(self.cfg_scale), stage)     # ring slot of the speculative frame's chunk (stage), or None
         if on_enqueued is not None:
             on_enqueued()          # e.g. hand the previous frame's audio to the streamer: it completes before this step's token
         self._tok_event.synchronize()
@@ -466,7 +502,7 @@ class Engine:
         return k
 
     def take_chunk(self, k: int) -> torch.Tensor:
-        """Wait for slot k's copy and return its samples (a fresh CPU tensor: the slot is reused three frames later)."""
+        """Wait for slot k's copy and return its samples (a fresh CPU tensor: the slot is reused seven frames later)."""
         self._ring_ev[k].synchronize()
         return self._ring[k].clone()
 

@@ -800,7 +800,7 @@ class VibeVoiceForConditionalGenerationInference:
                 # made for a mis-speculated frame is kept for the next real one (same RNG sequence).
                 if pending_nz is None:
                     pending_nz = draw(frame)
-                tok = eng.step_decode_speculative(ST_dev, SD, forced, *pending_nz, on_enqueued=hook)
+                tok = eng.step_decode_speculative(ST_dev, SD, forced, *pending_nz, on_enqueued=hook, stage=audio_streamer is not None)
                 speculated = True
                 if tok != SD:
                     eng.rollback_speech_state()
@@ -819,16 +819,17 @@ class VibeVoiceForConditionalGenerationInference:
                 with torch.cuda.stream(eng.stream):
                     eng.reset_speech_caches()
             if tok == SD:                                                                       # :571-670
+                slot = eng.spec_slot if speculated else None
                 if not speculated:
                     if pending_nz is None:
                         pending_nz = draw(frame)
-                    eng.step_speech(*pending_nz)
+                    slot = eng.step_speech(*pending_nz, stage=audio_streamer is not None)
                 pending_nz = None
                 with torch.cuda.stream(eng.stream):
                     chunk = eng.wav.clone()
                 chunks.append(chunk)
                 if audio_streamer is not None:
-                    staged.append(eng.stage_chunk())
+                    staged.append(slot if slot is not None else eng.stage_chunk())     # the copy went out right behind the acoustic decoder
                     if len(staged) > 2:
                         deliver()
                 frame += 1
