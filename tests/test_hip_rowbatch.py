@@ -363,3 +363,42 @@ def test_frag_flag_is_rejected_where_nothing_reads_that_layout(lib):
         a.m = m
         assert lib.vv_linear(C.byref(a), torch.cuda.current_stream().cuda_stream) != 0, f"m={m}"
         assert b"FRAG" in lib.vv_last_error()
+
+
+def test_generate_row_batch_1p5b_bf16_vs_oracle(big):
+    """The row-batched path at the benchmark's REAL shapes against the CPU oracle: VibeVoice-1.5B, bf16 weights (the oracle computes in fp32 on
+    the same bf16-rounded matrices, bf16 timestep quirk on), ONE generate() call on 3 dialogues - a shared 2-frame voice prompt, a 40-token
+    prompt, different schedules (a turn switch with a rolled-back speculative frame, an early end) and noise - each dialogue against its own
+    oracle run at the bf16 bar (2e-2), the lanes' error next to it in the parity record."""
+    from oracle import vv_oracle as O
+    cfg, sd, m = big
+    V = cfg.vocab
+    ST, SE, SD, EOS = V - 4, V - 3, V - 2, V - 1
+    g = torch.Generator().manual_seed(53)
+    ids = torch.cat([torch.randint(0, 1000, (39,), generator=g), torch.tensor([ST])])
+    forced = [[SD, SD, SE, ST, SD, SE, EOS], [SD, SD, SD, SE, EOS], [SD, SE, EOS]]
+    noise = torch.randn(3, 4, cfg.latent, generator=g)
+    voice = 0.1 * torch.randn(1, 2 * cfg.hop - 321, generator=g)
+    sp_mask = torch.zeros(40, dtype=torch.bool)
+    sp_mask[7:9] = True
+    speech_masks = torch.ones(1, 2, dtype=torch.bool)
+    std_noise, eps_noise = torch.randn(1, generator=g), torch.randn(1, 2, cfg.ac_dim, generator=g)
+    tok = _Tok(V)
+    tok.pad_id = 0
+    kw = dict(input_ids=ids[None].repeat(3, 1), attention_mask=torch.ones(3, 40, dtype=torch.long), speech_tensors=voice.repeat(3, 1),
+              speech_masks=speech_masks.repeat(3, 1), speech_input_mask=sp_mask[None].repeat(3, 1), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced,
+              noise=noise, speech_noise=(std_noise.repeat(3), eps_noise.repeat(3, 1, 1)))
+    outs = {rbm: m.generate(row_batch=rbm, **kw) for rbm in (True, False)}
+    torch.set_num_threads(16)
+    sd_o = {k: v.float().cpu() for k, v in sd.items()}
+    ocfg = cfg.as_dict()
+    _, conn = O.process_speech_inputs(sd_o, ocfg, voice, speech_masks, std_noise, eps_noise)
+    special = dict(speech_start=ST, speech_end=SE, speech_diffusion=SD, eos=EOS)
+    for b in range(3):
+        ref = O.generate(sd_o, ocfg, ids.tolist(), sp_mask, conn, special, noise[b], cfg_scale=2.0, n_steps=20, forced_tokens=forced[b], bf16_t=True)
+        want = torch.cat(ref.audio).numpy()
+        got = outs[True].speech_outputs[b][0].float().cpu().numpy()
+        assert got.shape == want.shape
+        e_rows = rel_rms(got, want, what=f"generate() 3 dialogues, 1.5B bf16, ROW-BATCHED vs oracle, dialogue {b}")
+        e_lane = rel_rms(outs[False].speech_outputs[b][0].float().cpu().numpy(), want, what=f"generate() 3 dialogues, 1.5B bf16, lanes vs oracle, dialogue {b}")
+        assert e_rows < 2e-2, f"row-batched dialogue {b} at 1.5B: waveform rel RMS {e_rows:.3e} vs oracle (lanes: {e_lane:.3e})"
