@@ -35,7 +35,7 @@ enum { VV_ACT_NONE = 0, VV_ACT_GELU = 1, VV_ACT_SWIGLU = 2 };
 /* vv_lin_args.flags: bf16 activation hand-off between two matrix-core GEMMs (x / out point at bf16 [m, ld] arrays, no
  * prologue on a bf16 x), a hint that the weights are re-read soon (keep them cacheable instead of streaming them
  * non-temporally: the diffusion head's matrices are reused by every one of the N solver steps of a frame), and
- * VV_LIN_W_FRAG: w / w2 point at the fragment-major copies of the matrices (vv_llm_layer.f_*; 5..8 rows, bf16, n % 16 == 0,
+ * VV_LIN_W_FRAG: w / w2 point at the fragment-major copies of the matrices (vv_llm_layer.f_*; 3..8 rows, bf16, n % 16 == 0,
  * k % 32 == 0 - any other call with this flag is an error) */
 enum { VV_LIN_X_BF16 = 1, VV_LIN_OUT_BF16 = 2, VV_LIN_W_REUSED = 4, VV_LIN_W_FRAG = 8 };
 
@@ -176,7 +176,7 @@ typedef struct vv_llm_layer {
   const void* wup;
   const void* wdown; /* [hidden, inter] */
   vv_w8 q_qkv, q_o, q_gate, q_up, q_down;
-  /* optional fragment-major copies of the five matrices (NULL: none) for a row-batched decode step (5..8 rows = {positive, negative} x up to 4
+  /* optional fragment-major copies of the five matrices (NULL: none) for a row-batched decode step (4..8 rows = {positive, negative} x 2..4
    * dialogues, vv_gemv_rows.hip): [N / 16][K / 32][4][16][8], i.e. element (16 g + n, 32 j + 8 c + e) of the row-major matrix at
    * ((g * K/32 + j) * 64 + 16 c + n) * 8 + e - one matrix-core B fragment per 1 KB of contiguous memory.  N % 16 == 0, K % 32 == 0. */
   const void* f_qkv; const void* f_o; const void* f_gate; const void* f_up; const void* f_down;

@@ -48,7 +48,7 @@ def _frag(w):
     return DeviceWeights.frag_major(w)
 
 
-@pytest.mark.parametrize("m_rows", [5, 8])
+@pytest.mark.parametrize("m_rows", [4, 5, 8])
 @pytest.mark.parametrize("frag", [False, True])
 @pytest.mark.parametrize("shape", [(4608, 1536, True, 1, True, False), (1536, 4608, False, 0, False, True), (2048, 1536, False, 1, False, False),
                                    (1536, 1536, False, 0, False, True), (8960, 1536, True, 1, False, False), (1536, 8960, False, 0, False, True),
@@ -359,7 +359,7 @@ def test_frag_flag_is_rejected_where_nothing_reads_that_layout(lib):
     a = L.LinArgs()
     a.x, a.ldx, a.n, a.k, a.wdt = x.data_ptr(), 8960, 1536, 8960, L.VV_BF16
     a.w, a.flags, a.out, a.ldo = w.data_ptr(), L.LIN_W_FRAG, out.data_ptr(), 1536
-    for m in (2, 8):
+    for m in (2, 8):      # 2 rows: never this kernel; 8 rows: no split-K scratch for the long-K shape
         a.m = m
         assert lib.vv_linear(C.byref(a), torch.cuda.current_stream().cuda_stream) != 0, f"m={m}"
         assert b"FRAG" in lib.vv_last_error()

@@ -21,7 +21,7 @@ int vv_set_error(int code, const char* fmt, ...);
   } while (0)
 
 int vv_launch_gemv_stream(const vv_lin_args& a, hipStream_t s);   // vv_gemv_stream.hip: 1 = launched, 0 = not covered
-// vv_gemv_rows.hip: 5..8 activation rows on the matrix cores; 1 launched, 0 not covered, < 0 error.  part / tickets: split-K workspace
+// vv_gemv_rows.hip: 3..8 activation rows on the matrix cores; 1 launched, 0 not covered, < 0 error.  part / tickets: split-K workspace
 // (vv_gemv_rows_part_floats / vv_gemv_rows_tickets give the sizes; tickets zero on entry, left zero) or null
 int vv_launch_gemv_rows(const vv_lin_args& a, float* part, size_t part_floats, int* tickets, size_t n_tickets, hipStream_t s);
 size_t vv_gemv_rows_part_floats(int n, int dual);

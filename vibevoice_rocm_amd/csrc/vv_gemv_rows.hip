@@ -1,5 +1,5 @@
-// vv_gemv_rows.hip — the weight-streaming GEMV for 5 .. 8 activation rows (dialogues batched into the row dimension: rows = {positive,
-// negative} x up to 4 dialogues), on the matrix cores.
+// vv_gemv_rows.hip — the weight-streaming GEMV for 3 .. 8 activation rows (dialogues batched into the row dimension: rows = {positive,
+// negative} x 2 .. 4 dialogues), on the matrix cores.
 //
 // Roofline: HBM.  The VALU GEMV (vv_gemv_stream.hip) keeps M x K/wave activations in registers and spends M FMAs per weight: its time grows
 // 1.2 - 1.6 us per row and M = 8 does not fit its registers at all for K > 1024.  Here one v_mfma_f32_16x16x32_bf16 consumes a wave's 1 KB
@@ -392,7 +392,7 @@ int vv_gemv_rows_init() {
 // 1 launched, 0 not covered (the caller falls back), < 0 error.  part / tickets: split-K workspace (tickets zeroed by the caller once; every
 // launch leaves them zero) or null (then only shapes that need no K split are taken).
 int vv_launch_gemv_rows(const vv_lin_args& a, float* part, size_t part_floats, int* tickets, size_t n_tickets, hipStream_t s) {
-  if (!g_rows_on || a.wdt != VV_BF16 || a.m < 5 || a.m > 8 || a.k % 32 || a.k < 32) return 0;
+  if (!g_rows_on || a.wdt != VV_BF16 || a.m < 3 || a.m > 8 || a.k % 32 || a.k < 32) return 0;
   if (a.pro == VV_PRO_SILU || (a.flags & (VV_LIN_X_BF16 | VV_LIN_OUT_BF16)) || a.ldx == 0) return 0;
   if ((uintptr_t)a.w % 16 || (a.w2 && (uintptr_t)a.w2 % 16) || (uintptr_t)a.x % 16 || a.ldx % 4) return 0;
   if (a.norm_w && (uintptr_t)a.norm_w % 16) return 0;

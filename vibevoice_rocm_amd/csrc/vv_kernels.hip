@@ -39,7 +39,7 @@ extern "C" int vv_init(void) {
   VV_TRY(vv_gemv_rows_init());
   return vv_fused_init();
 }
-// process-wide split-K scratch of the 5..8-row matrix-core GEMV for PUBLIC vv_linear calls (micro-benchmarks and tests only, switched on by
+// process-wide split-K scratch of the 3..8-row matrix-core GEMV for PUBLIC vv_linear calls (micro-benchmarks and tests only, switched on by
 // vv_tune("gemv_rows_scratch", 1): one stream at a time).  The composites hand vv_linear_ws their own workspace instead.
 static float* g_rows_part = nullptr;
 static int* g_rows_tk = nullptr;
@@ -536,12 +536,12 @@ static int launch_linear(const vv_lin_args& a, hipStream_t s) {
   const bool w_al16 = ((uintptr_t)a.w % 16 == 0) && (!dual || (uintptr_t)a.w2 % 16 == 0);
   if (vv_launch_skinny(a, s)) return 0;                          // a few rows x K = 512..2560, plain epilogue: the resampling convs (vv_convffn.hip)
   if (a.m <= 8) {
-    if (a.m > 4 && g_rows_part) {                               // 5..8 rows on the matrix cores (process-wide scratch: see rows_scratch)
+    if (a.m > 2 && g_rows_part) {                               // 3..8 rows on the matrix cores (process-wide scratch: see rows_scratch)
       const int rc = vv_launch_gemv_rows(a, g_rows_part, G_ROWS_PART_FLOATS, g_rows_tk, G_ROWS_TICKETS, s);
       if (rc) return rc < 0 ? rc : 0;
     }
-    if (a.flags & VV_LIN_W_FRAG)                                // only the 5..8-row matrix-core GEMV reads the fragment-major layout
-      return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: VV_LIN_W_FRAG weights are read by the 5..8-row GEMV only (m=%d n=%d k=%d not covered)", a.m, a.n, a.k);
+    if (a.flags & VV_LIN_W_FRAG)                                // only the 3..8-row matrix-core GEMV reads the fragment-major layout
+      return vv_set_error(VV_E_UNSUPPORTED, "vv_linear: VV_LIN_W_FRAG weights are read by the 3..8-row matrix-core GEMV only (m=%d n=%d k=%d not covered)", a.m, a.n, a.k);
     if (vv_launch_gemv_stream(a, s)) return 0;                  // bf16 weight-streaming fast path (<= 4 rows; 5..8 rows when K splits to <= 2 units per wave)
     if (a.m > 4 && a.wdt == VV_BF16 && a.ldx != 0) {
       // 5..8 rows not covered above: two streaming passes of <= 4 rows (the LDS-staged kernel below is LDS-bandwidth bound at M = 8)
@@ -640,8 +640,8 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   if (a->act != VV_ACT_SWIGLU && a->w2) return vv_set_error(VV_E_ARG, "vv_linear: w2 given without SWIGLU");
   if (a->mod_scale && (!a->mod_shift || a->pro != VV_PRO_RMSNORM)) return vv_set_error(VV_E_ARG, "vv_linear: modulate needs RMSNORM prologue and shift");
   if (a->m > 8 && a->ldx == 0) return vv_set_error(VV_E_ARG, "vv_linear: broadcast rows (ldx=0) only for m<=8");
-  if ((a->flags & VV_LIN_W_FRAG) && (a->wdt != VV_BF16 || a->m < 5 || a->m > 8 || a->n % 16 || a->k % 32))
-    return vv_set_error(VV_E_ARG, "vv_linear: VV_LIN_W_FRAG needs bf16 weights, 5..8 rows, n %% 16 == 0 and k %% 32 == 0");
+  if ((a->flags & VV_LIN_W_FRAG) && (a->wdt != VV_BF16 || a->m < 3 || a->m > 8 || a->n % 16 || a->k % 32))
+    return vv_set_error(VV_E_ARG, "vv_linear: VV_LIN_W_FRAG needs bf16 weights, 3..8 rows, n %% 16 == 0 and k %% 32 == 0");
   if ((a->flags & (VV_LIN_X_BF16 | VV_LIN_OUT_BF16)) && (a->wdt != VV_BF16 || a->m <= 8 || a->k % 16))
     return vv_set_error(VV_E_ARG, "vv_linear: bf16 activation hand-off needs bf16 weights, m > 8 and k %% 16 == 0");
   hipStream_t s = (hipStream_t)stream;
@@ -666,10 +666,10 @@ extern "C" int vv_linear(const vv_lin_args* a, vv_stream_t stream) {
   return 0;
 }
 
-// vv_linear for the composites of a row-batched step: 5..8 rows go to the matrix-core GEMV with the caller's split-K workspace, on the
+// vv_linear for the composites of a row-batched step: 3..8 rows go to the matrix-core GEMV with the caller's split-K workspace, on the
 // fragment-major copies f1 / f2 of w / w2 when the model has them; shapes that kernel does not cover take vv_linear on the row-major matrices
 int vv_linear_ws(const vv_lin_args* a, const void* f1, const void* f2, float* part, size_t part_floats, int* tickets, size_t n_tickets, vv_stream_t stream) {
-  if (a && a->wdt == VV_BF16 && a->m > 4 && a->m <= 8 && a->x && a->w && a->out) {
+  if (a && a->wdt == VV_BF16 && a->m > 2 && a->m <= 8 && a->x && a->w && a->out) {
     vv_lin_args b = *a;
     if (f1 && (!b.w2 || f2)) { b.w = f1; if (b.w2) b.w2 = f2; b.flags |= VV_LIN_W_FRAG; }
     const int rc = vv_launch_gemv_rows(b, part, part_floats, tickets, n_tickets, (hipStream_t)stream);

@@ -68,7 +68,7 @@ extern "C" size_t vv_llm_ws_bytes(const vv_llm* m, int R) {
   return al((size_t)R * m->hidden) + al((size_t)R * qkv) + al((size_t)R * m->heads * m->head_dim) + al((size_t)R * m->inter) +
          al((size_t)R * m->head_dim) + (R >= VV_PREFILL_ROWS ? al((size_t)R * widest / 2 + 64) : 0) +
          al((size_t)VV_ATT_ROWS * m->heads * VV_ATT_PART_SPLITS * (m->head_dim + 2)) + al((size_t)VV_ATT_ROWS * m->heads) +   // split-key decode attention
-         ((R > 4 && R <= 8) ? al(rows_part_floats(m)) + al(rows_tickets(m)) : 0);                                            // split-K partials of the 5..8-row GEMV
+         ((R > 2 && R <= 8) ? al(rows_part_floats(m)) + al(rows_tickets(m)) : 0);                                            // split-K partials of the 3..8-row GEMV
 }
 
 extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, int64_t ldx, int R, const int* lens,
@@ -103,8 +103,8 @@ extern "C" int vv_llm_forward(const vv_llm* m, const vv_kv* kv, const float* x, 
     if (e != hipSuccess) return vv_set_error(VV_E_HIP, "vv_llm_forward: %s", hipGetErrorString(e));
   }
   void* xb2 = prefill ? (void*)act : nullptr;      // bf16 SwiGLU output [R, inter] lives in the (otherwise unused) fp32 act buffer
-  // 5..8 rows (dialogues batched into the row dimension): the matrix-core GEMV with its split-K workspace, fragment-major weights when the model has them
-  const bool rows8 = decode && R > 4 && R <= 8 && m->wdt == VV_BF16;
+  // 3..8 rows (dialogues batched into the row dimension): the matrix-core GEMV with its split-K workspace, fragment-major weights when the model has them
+  const bool rows8 = decode && R > 2 && R <= 8 && m->wdt == VV_BF16;
   float* rpart = nullptr;
   int* rtick = nullptr;
   size_t rpart_n = 0, rtick_n = 0;

@@ -533,7 +533,7 @@ class Engine:
                      "vv_encoder_forward")
         return out
 
-    def acoustic_encode_many(self, wavs: List[torch.Tensor], max_streams: int = 4) -> List[torch.Tensor]:
+    def acoustic_encode_many(self, wavs: List[torch.Tensor], max_streams: int = 4, side_streams: Optional[list] = None) -> List[torch.Tensor]:
         """The S voice prompts of a dialogue (modeling_vibevoice_inference.py:149-163 encodes them as one padded batch).  Each voice is an
         independent causal sequence with its own zero left context and its own ragged tail, so they are not stacked into the row
         dimension of one launch sequence (every conv / mixer would need per-segment halos); instead they run CONCURRENTLY on up to
@@ -543,7 +543,16 @@ class Engine:
             return [self.acoustic_encode(w) for w in wavs]
         pool = _IDLE_STREAMS.setdefault(str(self.device), [])
         n_side = min(max_streams, len(wavs)) - 1
-        side = [pool.pop() if pool else torch.cuda.Stream(self.device) for _ in range(n_side)]
+        # side_streams: streams the caller already owns (the lanes of a batch) are used before any is taken from the pool or created: with the
+        # lanes holding the pooled streams, every batched call would otherwise create three more (8 hardware queues: a batch of 5 on the lanes
+        # dropped from 62 to 35 audio-sec/s after a batch of 2 had run first)
+        lent, seen = [], {self.stream.cuda_stream}
+        for st in (side_streams or []):
+            if st.cuda_stream not in seen and len(lent) < n_side:
+                lent.append(st)
+                seen.add(st.cuda_stream)
+        own = [pool.pop() if pool else torch.cuda.Stream(self.device) for _ in range(n_side - len(lent))]
+        side = lent + own
         streams = [self.stream] + side
         outs = []
         try:
@@ -558,7 +567,7 @@ class Engine:
         finally:                                            # streams go back to the pool whatever happened (they are never just dropped)
             for st in side:
                 self.stream.wait_stream(st)
-                pool.append(st)
+            pool.extend(own)
         return outs
 
     def connector(self, which: str, x: torch.Tensor) -> torch.Tensor:

@@ -138,9 +138,9 @@ class VibeVoiceForConditionalGenerationInference:
         # launch a frame's diffusion tail right behind the LLM step while the host still waits for the token (rolled back when the
         # token is not speech_diffusion); results are identical either way (tests/test_hip_parity.py)
         self.speculative_frames = True
-        # batches of 3..4 dialogues: one weight pass per frame for all of them (rowbatch.py) instead of one per dialogue (lanes)
+        # batches of 2..8 dialogues: one weight pass per frame for all of them (rowbatch.py) instead of one per dialogue (lanes)
         self.row_batch = os.environ.get("VV_ROW_BATCH", "1") != "0"
-        self.row_batch_min = int(os.environ.get("VV_ROW_BATCH_MIN", "3"))      # 2 dialogues: the lanes win (60 vs 58 audio-sec/s)
+        self.row_batch_min = int(os.environ.get("VV_ROW_BATCH_MIN", "2"))      # 2 dialogues: 64 vs 58 audio-sec/s on the lanes
         self._rowbatch = {}
         # weight_quant="fp8": weight-only e4m3 companions for the per-frame weight-streaming GEMVs
         self.weight_quant = weight_quant
@@ -220,7 +220,8 @@ class VibeVoiceForConditionalGenerationInference:
         live = [i for i in range(S) if t_len[i] > 0]
         with torch.cuda.stream(eng.stream):
             st_dev = speech_tensors.to(self.device)
-        encoded = eng.acoustic_encode_many([st_dev[i, :t_len[i]] for i in live])      # the S voices run concurrently
+        encoded = eng.acoustic_encode_many([st_dev[i, :t_len[i]] for i in live],      # the S voices run concurrently, on the lanes' streams if there are lanes
+                                           side_streams=[e.stream for e in self._lanes[1:]])
         with torch.cuda.stream(eng.stream):
             for i, m in zip(live, encoded):
                 means[i, : m.shape[0]] = m

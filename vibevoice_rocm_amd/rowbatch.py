@@ -4,7 +4,7 @@
 B dialogues (2 <= B <= 4 per RowBatch; generate() runs 5..8 as two of them in one loop) share ONE chain for the two weight-heavy parts of a frame:
 
   graph A   Qwen2 decode step with R = 2 B rows (dialogue b = rows {2 b: positive, 2 b + 1: negative} of x, lens and one KV cache with 2 B
-            rows): every weight matrix is read once for all dialogues (5..8 rows: the matrix-core GEMV of csrc/vv_gemv_rows.hip on
+            rows): every weight matrix is read once for all dialogues (4..8 rows: the matrix-core GEMV of csrc/vv_gemv_rows.hip on
             fragment-major weight copies), then vv_llm_tail_batch = final norm, constrained logits, argmax / forced token and position
             bookkeeping per dialogue;
   graph H   vv_head_sample_batch: the CFG diffusion sampler for all B utterances, 2 B rows through every head matrix per solver step.
