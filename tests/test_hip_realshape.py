@@ -256,11 +256,15 @@ def test_batch_of_two_left_padded_matches_single(big):
     pad = torch.full((15,), tok.pad_id)
     batch = torch.stack([a_ids, torch.cat([pad, b_ids])])
     mask = torch.stack([torch.ones(41, dtype=torch.long), torch.cat([torch.zeros(15, dtype=torch.long), torch.ones(26, dtype=torch.long)])])
-    out = m.generate(input_ids=batch, attention_mask=mask, tokenizer=tok, cfg_scale=1.3, forced_tokens=forced, noise=noise)
+    out = m.generate(input_ids=batch, attention_mask=mask, tokenizer=tok, cfg_scale=1.3, forced_tokens=forced, noise=noise, row_batch=False)
     one = m.generate(input_ids=b_ids[None], tokenizer=tok, cfg_scale=1.3, forced_tokens=forced, noise=noise)
     assert len(out.speech_outputs) == 2 and out.sequences.shape == (2, 45)
-    assert torch.equal(out.speech_outputs[1], one.speech_outputs[0])
+    assert torch.equal(out.speech_outputs[1], one.speech_outputs[0])          # on the lanes: the single run's kernels, bit for bit
     assert out.sequences[1, :15].tolist() == [tok.pad_id] * 15
+    rows = m.generate(input_ids=batch, attention_mask=mask, tokenizer=tok, cfg_scale=1.3, forced_tokens=forced, noise=noise)      # default: row-batched (4 rows)
+    assert (2, 0) in m._rowbatch and rows.sequences.tolist() == out.sequences.tolist()
+    err = rel_rms(rows.speech_outputs[1].float().cpu().numpy(), one.speech_outputs[0].float().cpu().numpy(), what="batch of 2, row-batched (4 rows) vs the single run")
+    assert err < 1e-2, f"row-batched batch of 2: waveform rel RMS {err:.3e}"
 
 
 def test_do_sample_constrained_vocabulary(big):
