@@ -363,10 +363,14 @@ class RowBatch:
         while the main queue runs A and H slows every dependent launch there by ~6 us (graph A 1.35 -> 2.28 ms, H 1.72 -> 2.9 ms, measured with
         VV_RB_TIMING=1), so the lanes' queues stay EMPTY until their work can run.  With several row batches in one loop (more than 4 dialogues)
         the caller enqueues every batch's A and H first and the tails afterwards: a batch's tails then overlap the next batch's A and H."""
+        late = self.late_tails
+
         def tail(b):
             e = self.lanes[b]
             torch.cuda.set_device(self.device)
-            with torch.cuda.stream(e.stream):
+            if late and not self._on_main[b]:
+                self._head_event.synchronize()      # the worker itself waits for H: its launch goes out the moment the sampler is done, and needs
+            with torch.cuda.stream(e.stream):       # no stream-side wait on the event any more
                 e._run("RBconv", self._seq_conv, b, self.uid)
                 self._lane_done(b)
                 if self._timing is not None and self._tcur is not None:
@@ -374,18 +378,19 @@ class RowBatch:
                     ev.record(e.stream)
                     self._tcur["t"].append(ev)
 
-        # every cross-stream wait is issued HERE, by the thread that owns the main stream: a wait on an event of a stream that another thread is
-        # capturing (first use of a graph) is a capture-isolation error, and only this thread ever captures on the main stream
-        if self.late_tails:
-            self._head_event.synchronize()
         self._wait_jobs()       # another row batch's worker may still be feeding (first use: capturing on) one of these streams
         inline = []
         for b in which:
             if self._on_main[b]:
                 inline.append(b)
             else:
-                self.lanes[b].stream.wait_event(self._head_event)
+                if not late:
+                    # a cross-stream wait is issued HERE, by the thread that owns the main stream: a wait on an event of a stream that another
+                    # thread is capturing (first use of a graph) is a capture-isolation error, and only this thread captures on the main stream
+                    self.lanes[b].stream.wait_event(self._head_event)
                 _submit(self.lanes[b].stream, tail, b)
+        if late and inline:
+            self._head_event.synchronize()
         for b in inline:
             tail(b)             # this dialogue's tail rides the main stream, behind H
 
