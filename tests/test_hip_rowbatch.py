@@ -326,8 +326,8 @@ def test_generate_row_batch_mid_bf16_vs_oracle():
 
 @pytest.mark.parametrize("B", [6, 8])
 def test_generate_two_row_batches_vs_lanes(big, B):
-    """5..8 dialogues: two row batches (3 + 3, 4 + 4) inside one lock-step loop, both on the main stream, the second batch's lanes sharing the HIP
-    streams of the first's - against the lanes: same sequences, waveforms to the bf16 noise floor."""
+    """5..8 dialogues: two row batches (3 + 3, 4 + 4) inside one lock-step loop, both on the main stream, their conv tails on the three side
+    streams (two lanes per stream, one launch worker per stream) - against the lanes: same sequences, waveforms to the bf16 noise floor."""
     cfg, sd, m = big
     tok = _Tok(cfg.vocab)
     D, E, EOS, S = tok.speech_diffusion_id, tok.speech_end_id, tok.eos_token_id, tok.speech_start_id
@@ -340,7 +340,7 @@ def test_generate_two_row_batches_vs_lanes(big, B):
     rows = m.generate(row_batch=True, **kw)
     lanes = m.generate(row_batch=False, **kw)
     n0 = (B + 1) // 2
-    assert (n0, 0) in m._rowbatch and (B // 2, n0) in m._rowbatch
+    assert (n0, 0, "side") in m._rowbatch and (B // 2, n0, "side") in m._rowbatch      # two row batches, every conv tail beside the main stream
     assert rows.sequences.tolist() == lanes.sequences.tolist()
     for b in range(B):
         assert rows.speech_outputs[b].shape == lanes.speech_outputs[b].shape
