@@ -768,6 +768,10 @@ def main():
                 lanes = batched_leg(model, cfg, args, args.batched, row_batch=False)
                 result["batched_generate"]["lanes_value"] = lanes["value"]
                 log(f"batched x{args.batched} on lanes: {lanes['value']} audio-sec/s aggregate")
+            if model.row_batch and args.batched == 4:
+                # 8 dialogues in one call: two row batches in one loop, every conv tail beside the main stream (modeling._generate_rowbatch)
+                result["batched_generate_x8"] = batched_leg(model, cfg, args, 8)
+                log(f"batched x8: {result['batched_generate_x8']['value']} audio-sec/s aggregate")
         except Exception as e:      # noqa: BLE001
             result["batched_generate"] = {"error": repr(e)}
             log(f"batched leg failed: {e!r}")
