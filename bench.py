@@ -346,7 +346,7 @@ def batched_leg(model, cfg, args, batch=4, row_batch=None):
         n = sum(o.shape[-1] for o in out.speech_outputs)
     assert n == batch * args.frames * cfg.hop, (n, batch, args.frames)
     dt = sorted(dts)[len(dts) // 2]
-    rowb = (model.row_batch if row_batch is None else row_batch) and 2 < batch <= 8
+    rowb = (model.row_batch if row_batch is None else row_batch) and 2 <= batch <= 16
     return dict(batch=batch, value=round(n / 24000.0 / dt, 3), unit="audio-sec/s", seconds=round(dt, 3), row_batched=bool(rowb),
                 runs=[round(n / 24000.0 / d, 2) for d in dts],
                 note="one generate() call on a batch of dialogues of the headline shape, in lock step; " +
@@ -763,7 +763,7 @@ def main():
         try:
             result["batched_generate"] = batched_leg(model, cfg, args, args.batched)
             log(f"batched x{args.batched}: {result['batched_generate']['value']} audio-sec/s aggregate")
-            if model.row_batch and 2 < args.batched <= 8:
+            if model.row_batch and 2 <= args.batched <= 16:
                 # the same call with the dialogues on one engine lane each (one LLM / head weight pass per dialogue and frame), for comparison
                 lanes = batched_leg(model, cfg, args, args.batched, row_batch=False)
                 result["batched_generate"]["lanes_value"] = lanes["value"]

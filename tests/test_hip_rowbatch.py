@@ -324,9 +324,9 @@ def test_generate_row_batch_mid_bf16_vs_oracle():
         assert e_rows < 2e-2, f"row-batched dialogue {b}: waveform rel RMS {e_rows:.3e} vs oracle (lanes: {e_lane:.3e})"
 
 
-@pytest.mark.parametrize("B", [6, 8])
+@pytest.mark.parametrize("B", [6, 8, 9])
 def test_generate_two_row_batches_vs_lanes(big, B):
-    """5..8 dialogues: two row batches (3 + 3, 4 + 4) inside one lock-step loop, both on the main stream, their conv tails on the three side
+    """5..16 dialogues: ceil(B / 4) row batches (3 + 3, 4 + 4, 3 + 3 + 3) inside one lock-step loop, both on the main stream, their conv tails on the three side
     streams (two lanes per stream, one launch worker per stream) - against the lanes: same sequences, waveforms to the bf16 noise floor."""
     cfg, sd, m = big
     tok = _Tok(cfg.vocab)
@@ -339,8 +339,9 @@ def test_generate_two_row_batches_vs_lanes(big, B):
     kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), tokenizer=tok, cfg_scale=2.0, forced_tokens=forced, noise=noise)
     rows = m.generate(row_batch=True, **kw)
     lanes = m.generate(row_batch=False, **kw)
-    n0 = (B + 1) // 2
-    assert (n0, 0, "side") in m._rowbatch and (B // 2, n0, "side") in m._rowbatch      # two row batches, every conv tail beside the main stream
+    n_groups = -(-B // 4)
+    sizes = [B // n_groups + (1 if g < B % n_groups else 0) for g in range(n_groups)]
+    assert all((n, sum(sizes[:g]), "side") in m._rowbatch for g, n in enumerate(sizes))      # ceil(B / 4) row batches, every conv tail beside the main stream
     assert rows.sequences.tolist() == lanes.sequences.tolist()
     for b in range(B):
         assert rows.speech_outputs[b].shape == lanes.speech_outputs[b].shape

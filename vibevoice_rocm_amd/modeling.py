@@ -290,7 +290,7 @@ class VibeVoiceForConditionalGenerationInference:
                 raise NotImplementedError("refresh_negative=False is built for batch size 1 only")
             rb = kwargs.get("row_batch", self.row_batch)
             fn = self._generate_lockstep
-            if rb and self.row_batch_min <= B <= 8 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
+            if rb and self.row_batch_min <= B <= 16 and sample_fn is None and self.dtype == torch.bfloat16 and self.weight_quant is None and not self.engine.sde:
                 fn = self._generate_rowbatch      # dialogues batched into the row dimension of the LLM / diffusion-head weight passes (rowbatch.py)
             return fn(input_ids, attention_mask, speech_input_mask, conn_all, special, cfg_scale, max_new_tokens, max_length_times,
                                            forced_tokens, None if noise is None else torch.as_tensor(noise), None if sde_noise is None else torch.as_tensor(sde_noise),
@@ -553,8 +553,8 @@ class VibeVoiceForConditionalGenerationInference:
                            forced_tokens, noise, sde_noise, audio_streamer, stop_check_fn, verbose, sample_fn, tokenizer, return_speech, in_dev):
         """The lock-step loop of `_generate_lockstep` with the B dialogues batched into the ROW dimension of the weight-heavy half of a frame
         (rowbatch.RowBatch: one Qwen2 decode step with 2 B rows, one diffusion sampling with 2 B rows; the conv tokenizers stay per dialogue on
-        their lanes' streams).  5..8 dialogues run as TWO row batches inside the same loop, both on the main stream: each step enqueues A and H of
-        both, then the conv tails - a batch's tails overlap the other batch's A and H.  Token handling, the draws' order, speculation and rollback
+        their lanes' streams).  5..16 dialogues run as ceil(B / 4) row batches inside the same loop, all on the main stream: each step enqueues A and
+        H of every batch, then the conv tails - a batch's tails overlap the other batches' A and H.  Token handling, the draws' order, speculation and rollback
         are those of the lock-step loop; results agree with the lanes to the rounding of the matrix-core GEMV (activations as bf16 hi + lo,
         ~2e-6 relative per product)."""
         from .rowbatch import RowBatch
@@ -575,7 +575,8 @@ class VibeVoiceForConditionalGenerationInference:
         max_steps = min(max_length - Lp, int(max_length_times * Lp))                                # :420
         max_step_per_sample = [min(max_length - l, int(max_length_times * l)) for l in L0]          # :421
         groups, rb_of, loc, off = [], {}, {}, 0
-        for n in ([B] if B <= 4 else [(B + 1) // 2, B // 2]):
+        n_groups = -(-B // 4)                                                                       # row batches of <= 4 dialogues, sizes balanced
+        for n in [B // n_groups + (1 if g < B % n_groups else 0) for g in range(n_groups)]:
             idxs = list(range(off, off + n))
             key = (n, off) if lanes[0] is self._lanes[0] else (n, off, "side")
             rb = self._rowbatch.get(key)

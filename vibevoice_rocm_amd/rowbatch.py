@@ -134,6 +134,7 @@ class RowBatch:
         key = (name,) + tuple(args)
         g = self._graphs.get(key)
         if g is None:
+            _wait_all_jobs()          # no worker may be waiting on an event of this stream while it captures (another row batch's tails)
             self.stream.synchronize()
             self._ck(self.lib.vv_graph_begin(self.sp), "graph begin")
             try:
